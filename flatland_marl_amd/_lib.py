@@ -1,0 +1,71 @@
+"""ctypes binding of the C ABI declared in include/flmarl.h (libflmarl_hip.so).
+
+There is no CPU fallback: if the shared library is missing or a call fails,
+the caller gets an exception.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflmarl_hip.so")
+
+FLM_OK = 0
+AGENT_ERRORS = {2: IndexError, 3: KeyError, 4: AssertionError, 5: OverflowError}
+GRAPH_ERR_NODES, GRAPH_ERR_RAILS, GRAPH_ERR_CELLS, GRAPH_ERR_STATES = 1, 2, 4, 8
+MAX_NODES = 2048
+ABI_VERSION = 1
+
+_p = C.c_void_p
+_i = C.c_int
+
+_SIGNATURES = {
+    "flm_abi_version": [],
+    "flm_graph_build": [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
+    "flm_state_index": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p],
+    "flm_distance_bfs": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p],
+    "flm_shortest_paths": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p],
+    "flm_bitmaps": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
+    "flm_observations": [_p, _p, _i, _i, _i, _p, _p],
+}
+
+_lib = None
+
+
+class FlmError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def load():
+    """Load libflmarl_hip.so (built by __graft_entry__.build()); raises if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FlmError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+                           % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, args in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        if lib.flm_abi_version() != ABI_VERSION:
+            raise FlmError("libflmarl_hip.so ABI %d, expected %d" % (lib.flm_abi_version(), ABI_VERSION))
+        _lib = lib
+    return _lib
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous()
+    return t.data_ptr()
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != FLM_OK:
+        raise FlmError("%s failed with code %d" % (name, rc))

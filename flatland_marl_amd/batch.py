@@ -1,0 +1,213 @@
+"""Device-resident observation state for a batch of E independent environments.
+
+All environments of a batch share the grid size H x W, the agent count A and the
+prediction depth.  Everything lives in HBM as torch tensors; the kernels are the
+C ABI of include/flmarl.h.  E = 1 reproduces the single-environment objects of
+the reference (RailObsForRailEnv / ObsPreprocessor, see rail_observations.py and
+preprocessing.py in this package for the drop-in classes).
+
+Layout in HBM (E environments, A agents, Rp padded rails, T1 = depth + 1):
+  grid      [E,H,W]  uint16      node_id/cell_rail/cell_idx [E,H*W] int32
+  edge_info [E,capR,5] int32     pred [E,capCells*4,4] uint16
+  dist      [E,A,capCells*4] uint16 (one row per distinct target, tslot maps agents to rows)
+  path_cell/path_meta [E,A,Lcap]  int32 / uint32
+  maps      [E,A,plane_stride] int8,   plane = [Rp,T1] rows, plane_stride = Rp*T1 rounded up to 16
+  obs       [E,A,3,plane_stride] uint8 (own plane, positive heat, negative heat)
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, ptr
+
+READY_TO_DEPART, ACTIVE, DONE, DONE_REMOVED = 0, 1, 2, 3
+
+
+def times_per_cell(speed):
+    """int(np.reciprocal(speed)) as in the reference (src/rail_observations.py:75-76)."""
+    return np.reciprocal(np.asarray(speed, dtype=np.float64)).astype(np.int64).astype(np.int32)
+
+
+def _dev_i32(x, device):
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.int32), device=device)
+
+
+class ObservationBatch:
+    def __init__(self, grid, start_rc, direction, target_rc, speed, depth, max_rails=None, status=None,
+                 device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise _lib.FlmError("no GPU visible: the observation path has no CPU implementation")
+        _lib.load()
+        self.device = torch.device(device)
+        grid = np.ascontiguousarray(grid, dtype=np.uint16)
+        if grid.ndim == 2:
+            grid = grid[None]
+        self.E, self.H, self.W = grid.shape
+        start_rc = np.asarray(start_rc).reshape(self.E, -1, 2)
+        self.A = start_rc.shape[1]
+        target_rc = np.asarray(target_rc).reshape(self.E, self.A, 2)
+        self.depth, self.T1 = int(depth), int(depth) + 1
+        self.max_rails = max_rails
+        # uint16 has no arithmetic in torch; the kernels only need the bytes
+        self.grid = torch.as_tensor(grid.view(np.int16), device=self.device)
+        self.start_cell = _dev_i32(start_rc[..., 0] * self.W + start_rc[..., 1], self.device)
+        self.pos_cell = self.start_cell.clone()
+        self.direction = _dev_i32(np.asarray(direction).reshape(self.E, self.A), self.device)
+        self.target_cell = _dev_i32(target_rc[..., 0] * self.W + target_rc[..., 1], self.device)
+        self.tpc = _dev_i32(times_per_cell(speed).reshape(self.E, self.A), self.device)
+        st = np.zeros((self.E, self.A), np.int32) if status is None else np.asarray(status).reshape(self.E, self.A)
+        self.status = _dev_i32(st, self.device)
+        self.cap_cells = int((grid != 0).reshape(self.E, -1).sum(1).max())
+        if self.cap_cells * 4 >= 65535:
+            raise ValueError("more than 16383 rail cells per environment are not supported")
+        self.cap_cells = max(self.cap_cells, 1)
+        self.R = None
+        self.maps = None
+        self.obs = None
+        self.stream = torch.cuda.current_stream(self.device)
+
+    # ------------------------------------------------------------------ graph
+    def build_graph(self):
+        """Switch graph + cell->rail table (+ state numbering for the BFS)."""
+        E, H, W, dev = self.E, self.H, self.W, self.device
+        HW = H * W
+        capN = min(_lib.MAX_NODES, self.cap_cells)
+        capR = 2 * capN + 8
+        capC = 2 * self.cap_cells + 2 * (H + W)
+        i32 = dict(dtype=torch.int32, device=dev)
+        for attempt in range(3):
+            self.node_id = torch.empty((E, HW), **i32)
+            self.node_cell = torch.empty((E, capN), **i32)
+            self.edge_info = torch.empty((E, capR, 5), **i32)
+            self.edge_cell_off = torch.empty((E, capR + 1), **i32)
+            self.edge_cells = torch.empty((E, capC), **i32)
+            self.cell_rail = torch.empty((E, HW), **i32)
+            self.counts = torch.zeros((E, 4), **i32)
+            s = self.stream.cuda_stream
+            call("flm_graph_build", ptr(self.grid), E, H, W, capN, capR, capC, ptr(self.node_id), ptr(self.node_cell),
+                 ptr(self.edge_info), ptr(self.edge_cell_off), ptr(self.edge_cells), ptr(self.cell_rail),
+                 ptr(self.counts), s)
+            counts = self.counts.cpu().numpy()
+            errs = int(np.bitwise_or.reduce(counts[:, 3]))
+            if errs == 0:
+                break
+            if errs & _lib.GRAPH_ERR_NODES:
+                raise ValueError("more than %d switches in one environment" % _lib.MAX_NODES)
+            capR = max(capR, int(counts[:, 1].max()))
+            capC = max(capC, int(counts[:, 2].max()))
+        else:
+            raise _lib.FlmError("graph build did not converge")
+        self.capN, self.capR, self.capC = capN, capR, capC
+        self.num_nodes = counts[:, 0].copy()
+        self.R = counts[:, 1].copy()
+        need = int(self.R.max())
+        if self.max_rails is not None and self.max_rails < need:
+            # the reference fails in _fill_padding (src/preprocessing.py:19) with a numpy broadcast error
+            raise ValueError("could not broadcast: an environment has %d rails > max_rails=%d" % (need, self.max_rails))
+        self.Rp = max(need, 1) if self.max_rails is None else int(self.max_rails)
+        self.plane_stride = (self.Rp * self.T1 + 15) // 16 * 16
+        self.cell_idx = torch.empty((E, HW), **i32)
+        self.n_cells = torch.empty((E,), **i32)
+        self.pred = torch.empty((E, self.cap_cells * 4, 4), dtype=torch.int16, device=dev)
+        call("flm_state_index", ptr(self.grid), E, H, W, self.cap_cells, ptr(self.cell_idx), ptr(self.n_cells),
+             ptr(self.pred), ptr(self.counts), self.stream.cuda_stream)
+        return self
+
+    # ------------------------------------------------------------------ distances and paths
+    def compute_distances(self):
+        E, A, dev = self.E, self.A, self.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.tslot = torch.empty((E, A), **i32)
+        self.n_slots = torch.empty((E,), **i32)
+        self.slot_target = torch.empty((E, A), **i32)
+        self.dist = torch.empty((E, A, self.cap_cells * 4), dtype=torch.int16, device=dev)
+        call("flm_distance_bfs", ptr(self.pred), ptr(self.cell_idx), ptr(self.n_cells), ptr(self.target_cell), E, A,
+             self.H, self.W, self.cap_cells, ptr(self.tslot), ptr(self.n_slots), ptr(self.slot_target), ptr(self.dist),
+             self.stream.cuda_stream)
+        return self
+
+    def shortest_paths(self, max_depth=None, start_cell=None, start_dir=None):
+        """get_shortest_paths for every agent (src/utils/shortest_path.py:11-90)."""
+        E, A, dev = self.E, self.A, self.device
+        max_depth = self.T1 if max_depth is None else int(max_depth)
+        Lcap = max_depth + 1
+        path_cell = torch.empty((E, A, Lcap), dtype=torch.int32, device=dev)
+        path_meta = torch.empty((E, A, Lcap), dtype=torch.int32, device=dev)
+        path_len = torch.empty((E, A), dtype=torch.int32, device=dev)
+        sc = self.pos_cell if start_cell is None else start_cell
+        sd = self.direction if start_dir is None else start_dir
+        call("flm_shortest_paths", ptr(self.grid), ptr(self.cell_idx), ptr(self.dist), ptr(self.tslot), ptr(sc),
+             ptr(sd), ptr(self.target_cell), ptr(self.status), E, A, self.H, self.W, self.cap_cells, max_depth, Lcap,
+             ptr(path_cell), ptr(path_meta), ptr(path_len), self.stream.cuda_stream)
+        self.path_cell, self.path_meta, self.path_len, self.Lcap = path_cell, path_meta, path_len, Lcap
+        return self
+
+    # ------------------------------------------------------------------ bitmaps and observations
+    def bitmaps(self, shift=1, out=None):
+        """Occupancy planes of the current paths; shift=1 is get_many (src/rail_observations.py:78-95)."""
+        E, A, dev = self.E, self.A, self.device
+        if out is None:
+            out = torch.empty((E, A, self.plane_stride), dtype=torch.int8, device=dev)
+        self.agent_err = torch.empty((E, A), dtype=torch.int32, device=dev)
+        call("flm_bitmaps", ptr(self.path_cell), ptr(self.path_len), None, ptr(self.pos_cell), ptr(self.target_cell),
+             ptr(self.tpc), ptr(self.node_id), ptr(self.cell_rail), ptr(self.edge_info), E, A, A, self.H, self.W,
+             self.capR, self.Rp, self.T1, self.plane_stride, self.Lcap, int(shift), ptr(out), ptr(self.agent_err),
+             self.stream.cuda_stream)
+        self.maps = out
+        return out
+
+    def observations(self, maps=None, own=None, out=None):
+        """[E,A,3,plane_stride] uint8: own plane, positive heat, negative heat (src/preprocessing.py:24-30,61-74)."""
+        maps = self.maps if maps is None else maps
+        if self.A > 255:
+            raise ValueError("heat counts are stored in 8 bits: at most 255 agents per environment")
+        if out is None:
+            out = torch.empty((self.E, self.A, 3, self.plane_stride), dtype=torch.uint8, device=self.device)
+        call("flm_observations", ptr(maps), ptr(own), self.E, self.A, self.plane_stride, ptr(out),
+             self.stream.cuda_stream)
+        self.obs = out
+        return out
+
+    def reset(self):
+        """Graph, distances, shortest paths, occupancy planes: what env.reset() triggers in the reference."""
+        self.build_graph()
+        self.compute_distances()
+        self.shortest_paths()
+        return self.bitmaps(shift=1)
+
+    # ------------------------------------------------------------------ host views (tests, drop-in classes)
+    def maps_numpy(self, e=0, maps=None):
+        """[A,R_e,T1] int8 view of one environment, as the reference's get_many returns it."""
+        maps = self.maps if maps is None else maps
+        m = maps[e, :, : self.Rp * self.T1].reshape(self.A, self.Rp, self.T1)
+        return m[:, : int(self.R[e])].cpu().numpy()
+
+    def obs_numpy(self, e=0, obs=None):
+        """[A,3,Rp,T1] int16 of one environment (own plane sign-extended)."""
+        obs = self.obs if obs is None else obs
+        o = obs[e, :, :, : self.Rp * self.T1].reshape(self.A, 3, self.Rp, self.T1).cpu().numpy()
+        out = o.astype(np.int16)
+        out[:, 0] = o[:, 0].view(np.int8)
+        return out
+
+    def paths_numpy(self, e=0):
+        """List over agents of [n,7] int32 rows (r, c, heading, action, next r, next c, next heading) or None."""
+        W = self.W
+        pc = self.path_cell[e].cpu().numpy()
+        pm = self.path_meta[e].cpu().numpy().view(np.uint32)
+        pl = self.path_len[e].cpu().numpy()
+        dr = np.array([-1, 0, 1, 0])
+        dc = np.array([0, 1, 0, -1])
+        out = []
+        for a in range(self.A):
+            n = int(pl[a])
+            if n < 0:
+                out.append(None)
+                continue
+            cell, meta = pc[a, :n].astype(np.int64), pm[a, :n]
+            h, act, nh = meta & 0xFF, (meta >> 8) & 0xFF, (meta >> 16) & 0xFF
+            r, c = cell // W, cell % W
+            move = act != 4
+            rows = np.stack([r, c, h, act, r + np.where(move, dr[nh], 0), c + np.where(move, dc[nh], 0), nh], 1)
+            out.append(rows.astype(np.int32))
+        return out

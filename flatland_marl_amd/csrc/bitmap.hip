@@ -1,0 +1,250 @@
+// Path -> rail-occupancy plane, and the per-agent observation (own plane + two heat planes).
+#include "flm_common.h"
+
+namespace flm {
+
+// One 256-thread workgroup per (environment, path).  All threads clear the plane with 16-byte stores
+// while they look up, per time step, the cell the agent is predicted to occupy and the rail / node in
+// that cell.  Thread 0 then runs the short sequential pass that tracks through which node the agent
+// entered its current rail (that decides the sign) and back-fills the steps spent on switch cells
+// with the rail that follows.  After a barrier every step writes its single byte.
+__global__ __launch_bounds__(256) void bitmaps_kernel(
+    const int32_t* __restrict__ path_cell, const int32_t* __restrict__ path_len, const int32_t* __restrict__ agent_of,
+    const int32_t* __restrict__ pos_cell, const int32_t* __restrict__ target_cell, const int32_t* __restrict__ tpc_all,
+    const int32_t* __restrict__ node_id_all, const int32_t* __restrict__ cell_rail_all,
+    const int32_t* __restrict__ edge_info_all, int A, int n_paths, int H, int W, int capR, int Rp, int T1,
+    int plane_stride, int Lcap, int shift, int8_t* __restrict__ planes, int32_t* __restrict__ err_out) {
+  extern __shared__ __attribute__((aligned(16))) int lds[];
+  int* s_cell = lds;             // [T1] predicted cell
+  int* s_rail = lds + T1;        // [T1] rail in that cell or -1
+  int* s_node = lds + 2 * T1;    // [T1] node in that cell or -1
+  int* s_orail = lds + 3 * T1;   // [T1] rail to paint at the step, -1 = none
+  int* s_oval = lds + 4 * T1;    // [T1] its sign
+  int* s_misc = lds + 5 * T1;    // [0] kstop, [1] n (steps kept), [2] error
+  const int gp = blockIdx.x;
+  const int e = gp / n_paths, j = gp - e * n_paths;
+  const int a = agent_of ? agent_of[gp] : j;
+  const int HW = H * W;
+  const int tid = threadIdx.x;
+  const int ga = e * A + a;
+  const int pos = pos_cell[ga], tgt = target_cell[ga];
+  int tpc = tpc_all[ga];
+  if (tpc < 1) tpc = 1;
+  int len = path_len[gp];
+  if (len > Lcap) len = Lcap;
+  const int32_t* pcell = path_cell + (size_t)gp * Lcap;
+  const int32_t* node_id = node_id_all + (size_t)e * HW;
+  const int32_t* cell_rail = cell_rail_all + (size_t)e * HW;
+  const int32_t* edge_info = edge_info_all + (size_t)e * capR * 5;
+  int8_t* plane = planes + (size_t)gp * plane_stride;
+
+  if (tid == 0) {
+    s_misc[0] = len > 0 ? len - 1 : 0;
+    s_misc[1] = T1;
+    s_misc[2] = 0;
+  }
+  // clear the plane
+  {
+    uint4 z = make_uint4(0, 0, 0, 0);
+    uint4* p4 = reinterpret_cast<uint4*>(plane);
+    for (int i = tid; i < plane_stride / 16; i += 256) p4[i] = z;
+  }
+  __syncthreads();
+  // the agent stops advancing at the first path element on the target cell (element 0 is where it stands)
+  for (int k = tid; k < len; k += 256) {
+    int c = (k == 0) ? pos : pcell[k];
+    if (c == tgt) atomicMin(&s_misc[0], k);
+  }
+  __syncthreads();
+  const int kstop = s_misc[0];
+  for (int ts = tid; ts < T1; ts += 256) {
+    int k = ts / tpc;
+    if (k > kstop) k = kstop;
+    int c = (k == 0) ? pos : pcell[k];
+    s_cell[ts] = c;
+    bool inside = c >= 0 && c < HW;
+    s_rail[ts] = inside ? cell_rail[c] : -1;
+    s_node[ts] = inside ? node_id[c] : -1;
+    s_orail[ts] = -1;
+    if (c == tgt) atomicMin(&s_misc[1], ts + 1);  // cut after the first visit of the target
+  }
+  __syncthreads();
+  const int n = s_misc[1];
+  if (tid == 0) {
+    int err = 0;
+    int en = -1, ecp = -1;  // (node, cardinal point) through which the current rail was entered
+    int i = 0;
+    if (s_rail[0] != -1) {
+      const int initial = s_rail[0];
+      int rail = initial;
+      while (rail != -1) {
+        i++;
+        if (i >= n) { err = FLM_AGENT_INDEX_ERROR; break; }
+        rail = s_rail[i];
+      }
+      if (!err) {
+        int nid = s_node[i];
+        if (nid < 0) err = FLM_AGENT_KEY_ERROR;
+        else {
+          int c0 = s_cell[i - 1], c1 = s_cell[i];
+          int cp = (direction_to_point(c0 / W, c0 % W, c1 / W, c1 % W) + 2) & 3;
+          const int32_t* ei = edge_info + initial * 5;
+          if (nid == ei[2] && cp == ei[3]) { en = ei[0]; ecp = ei[1]; }
+          else if (nid == ei[0] && cp == ei[1]) { en = ei[2]; ecp = ei[3]; }
+        }
+      }
+    } else {
+      int nid = s_node[0];
+      if (nid < 0) err = FLM_AGENT_KEY_ERROR;
+      else if (n < 2) err = FLM_AGENT_INDEX_ERROR;
+      else {
+        int c0 = s_cell[0], c1 = s_cell[1];
+        en = nid;
+        ecp = direction_to_point(c0 / W, c0 % W, c1 / W, c1 % W);
+      }
+    }
+    int holes = 0;
+    for (int ts = 0; ts < n && !err; ts++) {
+      int rail = s_rail[ts];
+      if (rail == -1) {
+        holes++;
+        if (ts + 1 < n && s_cell[ts] != s_cell[ts + 1]) {
+          int nid = s_node[ts];
+          if (nid < 0) { err = FLM_AGENT_KEY_ERROR; break; }
+          int c0 = s_cell[ts], c1 = s_cell[ts + 1];
+          en = nid;
+          ecp = direction_to_point(c0 / W, c0 % W, c1 / W, c1 % W);
+        }
+      } else {
+        const int32_t* ei = edge_info + rail * 5;
+        int dir = 0;
+        if (en == ei[2] && ecp == ei[3]) dir = 1;
+        else if (en == ei[0] && ecp == ei[1]) dir = -1;
+        if (dir == 0) { err = FLM_AGENT_ASSERT_ERROR; break; }
+        for (int b = ts - holes; b <= ts; b++) {
+          s_orail[b] = rail;
+          s_oval[b] = dir;
+        }
+        holes = 0;
+      }
+    }
+    s_misc[2] = err;
+    err_out[gp] = err;
+  }
+  __syncthreads();  // also orders the clearing stores before the bytes written below
+  if (s_misc[2] == 0) {
+    for (int ts = tid; ts < n; ts += 256) {
+      int rail = s_orail[ts];
+      int t = ts + shift;
+      if (rail >= 0 && rail < Rp && t < T1) plane[(size_t)rail * T1 + t] = (int8_t)s_oval[ts];
+    }
+  }
+}
+
+// ---- observations ---------------------------------------------------------------------------------
+// A workgroup owns 1 KiB of plane positions (16 per lane) of one environment.  Its NW waves split the
+// agents; each wave keeps its agents' 16-byte pieces in registers, counts the +1 and the -1 entries in
+// packed bytes, the per-wave counts meet in LDS, and every wave then writes, for its agents, the own
+// plane and "total minus self" for both signs.  Each input byte is read once and each output byte
+// written once, all as 16-byte accesses of 1 KiB per wave instruction.
+__device__ __forceinline__ unsigned pos_bits(unsigned x) { return x & ~(x >> 1) & 0x01010101u; }
+__device__ __forceinline__ unsigned neg_bits(unsigned x) { return (x >> 1) & 0x01010101u; }
+__device__ __forceinline__ uint4 pos_bits4(uint4 v) { return make_uint4(pos_bits(v.x), pos_bits(v.y), pos_bits(v.z), pos_bits(v.w)); }
+__device__ __forceinline__ uint4 neg_bits4(uint4 v) { return make_uint4(neg_bits(v.x), neg_bits(v.y), neg_bits(v.z), neg_bits(v.w)); }
+__device__ __forceinline__ uint4 add4(uint4 a, uint4 b) { return make_uint4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ uint4 sub4(uint4 a, uint4 b) { return make_uint4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+template <int APW>
+__global__ __launch_bounds__(1024) void observations_kernel(const int8_t* __restrict__ maps, const int8_t* __restrict__ own,
+                                                            int A, int plane_stride, uint8_t* __restrict__ obs) {
+  extern __shared__ __attribute__((aligned(16))) uint4 part[];  // [nw][2][64]
+  const int nw = blockDim.x >> 6;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int e = blockIdx.y;
+  const size_t off = (size_t)blockIdx.x * 1024 + (size_t)lane * 16;
+  const bool active = off < (size_t)plane_stride;
+  const size_t env_base = (size_t)e * A;
+  uint4 v[APW];
+  uint4 psum = make_uint4(0, 0, 0, 0), nsum = make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < APW; i++) {
+    int a = wave + i * nw;
+    v[i] = make_uint4(0, 0, 0, 0);
+    if (active && a < A) v[i] = *reinterpret_cast<const uint4*>(maps + (env_base + a) * plane_stride + off);
+  }
+#pragma unroll
+  for (int i = 0; i < APW; i++) {
+    psum = add4(psum, pos_bits4(v[i]));
+    nsum = add4(nsum, neg_bits4(v[i]));
+  }
+  part[(wave * 2 + 0) * 64 + lane] = psum;
+  part[(wave * 2 + 1) * 64 + lane] = nsum;
+  __syncthreads();
+  uint4 ptot = make_uint4(0, 0, 0, 0), ntot = make_uint4(0, 0, 0, 0);
+  for (int w = 0; w < nw; w++) {
+    ptot = add4(ptot, part[(w * 2 + 0) * 64 + lane]);
+    ntot = add4(ntot, part[(w * 2 + 1) * 64 + lane]);
+  }
+#pragma unroll
+  for (int i = 0; i < APW; i++) {
+    int a = wave + i * nw;
+    if (active && a < A) {
+      uint4 mine = v[i];
+      uint4 shown = own ? *reinterpret_cast<const uint4*>(own + (env_base + a) * plane_stride + off) : mine;
+      uint8_t* o = obs + (env_base + a) * 3 * plane_stride + off;
+      *reinterpret_cast<uint4*>(o) = shown;
+      *reinterpret_cast<uint4*>(o + plane_stride) = sub4(ptot, pos_bits4(mine));
+      *reinterpret_cast<uint4*>(o + 2 * (size_t)plane_stride) = sub4(ntot, neg_bits4(mine));
+    }
+  }
+}
+
+}  // namespace flm
+
+extern "C" int flm_bitmaps(const int32_t* path_cell, const int32_t* path_len, const int32_t* agent_of,
+                           const int32_t* pos_cell, const int32_t* target_cell, const int32_t* tpc,
+                           const int32_t* node_id, const int32_t* cell_rail, const int32_t* edge_info, int E, int A,
+                           int n_paths, int H, int W, int capR, int Rp, int T1, int plane_stride, int Lcap, int shift,
+                           int8_t* planes, int32_t* err, void* stream) {
+  if (!path_cell || !path_len || !pos_cell || !target_cell || !tpc || !node_id || !cell_rail || !edge_info || !planes ||
+      !err)
+    return FLM_E_ARG;
+  if (E <= 0 || A <= 0 || n_paths <= 0 || H <= 0 || W <= 0 || capR <= 0 || Rp <= 0 || T1 <= 1 || Lcap <= 0 ||
+      shift < 0 || plane_stride % 16 != 0 || (long long)plane_stride < (long long)Rp * T1 || T1 > 8000)
+    return FLM_E_ARG;
+  if (!agent_of && n_paths != A) return FLM_E_ARG;
+  size_t lds = sizeof(int) * (5 * (size_t)T1 + 4);
+  hipLaunchKernelGGL(flm::bitmaps_kernel, dim3(E * n_paths), dim3(256), lds, (hipStream_t)stream, path_cell, path_len,
+                     agent_of, pos_cell, target_cell, tpc, node_id, cell_rail, edge_info, A, n_paths, H, W, capR, Rp, T1,
+                     plane_stride, Lcap, shift, planes, err);
+  FLM_CHECK_LAUNCH();
+  return FLM_OK;
+}
+
+template <int APW>
+static int launch_obs(const int8_t* maps, const int8_t* own, int E, int A, int plane_stride, uint8_t* obs, int nw,
+                      hipStream_t stream) {
+  dim3 grid((plane_stride + 1023) / 1024, E);
+  size_t lds = sizeof(uint4) * 2 * 64 * (size_t)nw;
+  hipLaunchKernelGGL(flm::observations_kernel<APW>, grid, dim3(nw * 64), lds, stream, maps, own, A, plane_stride, obs);
+  FLM_CHECK_LAUNCH();
+  return FLM_OK;
+}
+
+extern "C" int flm_observations(const int8_t* maps, const int8_t* own, int E, int A, int plane_stride, uint8_t* obs,
+                                void* stream_) {
+  if (!maps || !obs) return FLM_E_ARG;
+  if (E <= 0 || E > 65535 || A <= 0 || A > 255 || plane_stride <= 0 || plane_stride % 16 != 0) return FLM_E_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  int nw = A <= 64 ? 4 : (A <= 128 ? 8 : 16);
+  if (nw > A) nw = A;
+  int apw = (A + nw - 1) / nw;
+  if (apw <= 1) return launch_obs<1>(maps, own, E, A, plane_stride, obs, nw, stream);
+  if (apw <= 2) return launch_obs<2>(maps, own, E, A, plane_stride, obs, nw, stream);
+  if (apw <= 4) return launch_obs<4>(maps, own, E, A, plane_stride, obs, nw, stream);
+  if (apw <= 8) return launch_obs<8>(maps, own, E, A, plane_stride, obs, nw, stream);
+  if (apw <= 13) return launch_obs<13>(maps, own, E, A, plane_stride, obs, nw, stream);
+  return launch_obs<16>(maps, own, E, A, plane_stride, obs, nw, stream);
+}
+
+extern "C" int flm_abi_version(void) { return 1; }

@@ -1,0 +1,96 @@
+// Shared device helpers for the flatland-marl hot-path kernels (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/flmarl.h"
+
+#define FLM_WAVE 64
+
+#define FLM_CHECK_LAUNCH()                                  \
+  do {                                                      \
+    if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH; \
+  } while (0)
+
+namespace flm {
+
+__device__ __forceinline__ int dr(int h) { return (h == 0) ? -1 : ((h == 2) ? 1 : 0); }
+__device__ __forceinline__ int dc(int h) { return (h == 1) ? 1 : ((h == 3) ? -1 : 0); }
+__device__ __forceinline__ int nibble(unsigned code, int h) { return (code >> ((3 - h) * 4)) & 0xF; }
+__device__ __forceinline__ int has_exit(int nib, int n) { return (nib >> (3 - n)) & 1; }
+
+// Heading from cell p1 towards cell p2 (row axis wins ties; equal cells give South).
+__device__ __forceinline__ int direction_to_point(int r1, int c1, int r2, int c2) {
+  int a = r1 - r2, b = c1 - c2;
+  if (a * a >= b * b) return a > 0 ? 0 : 2;
+  return b > 0 ? 3 : 1;
+}
+
+// Candidate moves of an agent heading h in a cell, in the order left, forward, right.
+// act[i] in {1,2,3}; nd[i] = new heading.  Returns the count (0..3).
+__device__ __forceinline__ int valid_moves(unsigned code, int h, int* act, int* nd) {
+  int nib = nibble(code, h);
+  int n = 0;
+  if (__popc(code & 0xFFFFu) == 1) {  // dead end: only the U-turn, reported as "forward"
+    int ex = (h + 2) & 3;
+    if (has_exit(nib, ex)) { act[0] = 2; nd[0] = ex; n = 1; }
+  } else {
+    bool single = __popc(nib) == 1;
+#pragma unroll
+    for (int i = -1; i <= 1; i++) {
+      int d = (h + i + 4) & 3;
+      if (has_exit(nib, d)) { act[n] = single ? 2 : 2 + i; nd[n] = d; n++; }
+    }
+  }
+  return n;
+}
+
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+  unsigned lane = threadIdx.x & 63;
+  return (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+}
+
+// Exclusive prefix of a per-thread flag over a 256-thread block, plus the block total.
+// scratch: 4 ints of LDS; contains two barriers.
+__device__ __forceinline__ int block_flag_scan256(bool flag, int* scratch, int* total) {
+  unsigned long long m = __ballot(flag);
+  int w = threadIdx.x >> 6;
+  int within = __popcll(m & lanemask_lt());
+  if ((threadIdx.x & 63) == 0) scratch[w] = __popcll(m);
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int v = scratch[i];
+    if (i < w) base += v;
+    tot += v;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + within;
+}
+
+// Exclusive prefix sum of a per-thread int over a 256-thread block, plus the block total.
+__device__ __forceinline__ int block_int_scan256(int v, int* scratch, int* total) {
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) scratch[w] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int s = scratch[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+}  // namespace flm

@@ -1,0 +1,257 @@
+// Switch-graph construction, one 256-thread workgroup per environment.
+//
+// The numbering the sequential definition produces (src/rail_observations.py:410-510 of the
+// reference) is reproduced without a sequential pass:
+//   * nodes are numbered row-major  -> ballot/prefix scan over the cells;
+//   * every (node, cardinal point) "port" that has a connection walks the rail to the next node,
+//     independently of all other ports (parallel);
+//   * the sequential rule "create the edge unless the far port was already visited" is equivalent to:
+//     port p (index 4*node+cp) with far port q creates an edge iff q was not itself processed at or
+//     before p (q has no connection, or q > p) and p is the lowest such port reaching q.  Edge ids
+//     are the prefix count of creating ports in port order.
+#include "flm_common.h"
+
+namespace flm {
+
+struct Walk {
+  int end_port;  // 4*node2 + cp2, or -1 when the walk makes no edge
+  int len;       // cells strictly between the two nodes
+};
+
+// Follows the rail leaving cell `cell` towards heading `dir` until a node is met.
+// EMIT: also writes the cells (cell*4+heading) to out[] and lowers cell_rail[] to `rail`.
+template <bool EMIT>
+__device__ Walk walk_rail(const uint16_t* __restrict__ grid, const int32_t* __restrict__ node_id, int H, int W,
+                          int cell, int dir, int32_t* out, int out_cap, int32_t* cell_rail, int rail) {
+  Walk w;
+  w.end_port = -1;
+  w.len = 0;
+  int r = cell / W, c = cell - r * W;
+  const int cap_steps = 4 * H * W;  // the sequential definition does not terminate on a cycle of plain cells
+  for (int step = 0; step < cap_steps; step++) {
+    int nr = r + dr(dir), nc = c + dc(dir);
+    if (nr < 0 || nr >= H || nc < 0 || nc >= W) return w;  // leaves the grid: no edge
+    int ncell = nr * W + nc;
+    int id2 = node_id[ncell];
+    if (id2 >= 0) {
+      w.end_port = id2 * 4 + ((dir + 2) & 3);
+      return w;
+    }
+    if (EMIT) {
+      if (w.len < out_cap) out[w.len] = ncell * 4 + dir;
+      atomicMin(reinterpret_cast<unsigned*>(cell_rail) + ncell, (unsigned)rail);
+    }
+    w.len++;
+    r = nr;
+    c = nc;
+    // next heading: first allowed exit other than the side we came from; North when there is none
+    int nib = nibble(grid[ncell], dir) & ~(1 << (3 - ((dir + 2) & 3)));
+    int t = nib ? (3 - (31 - __clz(nib))) : 0;
+    int tr = r + dr(t), tc = c + dc(t);
+    if (tr < 0 || tr >= H || tc < 0 || tc >= W) return w;
+    dir = t;
+  }
+  w.end_port = -1;
+  return w;
+}
+
+__global__ __launch_bounds__(256) void graph_build_kernel(
+    const uint16_t* __restrict__ grid_all, int H, int W, int capN, int capR, int capC, int32_t* __restrict__ node_id_all,
+    int32_t* __restrict__ node_cell_all, int32_t* __restrict__ edge_info_all, int32_t* __restrict__ edge_cell_off_all,
+    int32_t* __restrict__ edge_cells_all, int32_t* __restrict__ cell_rail_all, int32_t* __restrict__ counts_all) {
+  extern __shared__ __attribute__((aligned(16))) int lds[];
+  const int e = blockIdx.x;
+  const int HW = H * W;
+  const uint16_t* grid = grid_all + (size_t)e * HW;
+  int32_t* node_id = node_id_all + (size_t)e * HW;
+  int32_t* node_cell = node_cell_all + (size_t)e * capN;
+  int32_t* edge_info = edge_info_all + (size_t)e * capR * 5;
+  int32_t* edge_cell_off = edge_cell_off_all + (size_t)e * (capR + 1);
+  int32_t* edge_cells = edge_cells_all + (size_t)e * capC;
+  int32_t* cell_rail = cell_rail_all + (size_t)e * HW;
+  int32_t* counts = counts_all + (size_t)e * 4;
+
+  int* scratch = lds;                 // 8 ints
+  int* p_end = lds + 8;               // [4*capN]
+  int* p_len = p_end + 4 * capN;      // [4*capN]
+  int* p_first = p_len + 4 * capN;    // [4*capN]
+  int* conn = p_first + 4 * capN;     // [capN] connection mask per node
+  const int tid = threadIdx.x;
+  int err = 0;
+
+  // ---- nodes: row-major numbering
+  int n_nodes = 0;
+  for (int base = 0; base < HW; base += 256) {
+    int cell = base + tid;
+    bool is_node = false;
+    int mask = 0;
+    if (cell < HW) {
+      unsigned code = grid[cell];
+      if (code == 0x8421u) {
+        is_node = true;
+        mask = 0xF;
+      } else {
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          int nib = nibble(code, d);
+          if (nib) mask |= 1 << ((d + 2) & 3);
+#pragma unroll
+          for (int t = 0; t < 4; t++)
+            if (has_exit(nib, t)) mask |= 1 << t;
+          if (__popc(nib) > 1) is_node = true;
+        }
+      }
+      cell_rail[cell] = -1;
+    }
+    int tot;
+    int id = n_nodes + block_flag_scan256(is_node, scratch, &tot);
+    if (cell < HW) node_id[cell] = (is_node && id < capN) ? id : -1;
+    if (is_node && id < capN) {
+      node_cell[id] = cell;
+      conn[id] = mask;
+    }
+    n_nodes += tot;
+  }
+  if (n_nodes > capN) {
+    err |= FLM_GRAPH_ERR_NODES;
+    n_nodes = capN;
+  }
+  __syncthreads();  // node_id / node_cell / conn visible to the whole workgroup
+
+  // ---- every connected port walks to the next node
+  const int n_ports = n_nodes * 4;
+  for (int p = tid; p < n_ports; p += 256) {
+    p_first[p] = 0x7FFFFFFF;
+    p_end[p] = -1;
+    p_len[p] = 0;
+    int n = p >> 2, cp = p & 3;
+    if ((conn[n] >> cp) & 1) {
+      Walk w = walk_rail<false>(grid, node_id, H, W, node_cell[n], cp, nullptr, 0, nullptr, 0);
+      p_end[p] = w.end_port;
+      p_len[p] = w.len;
+    }
+  }
+  __syncthreads();
+  for (int p = tid; p < n_ports; p += 256) {
+    int q = p_end[p];
+    if (q >= 0) {
+      bool q_done_before = ((conn[q >> 2] >> (q & 3)) & 1) && q <= p;
+      if (q_done_before) p_end[p] = -1;  // not a candidate
+      else atomicMin(&p_first[q], p);
+    }
+  }
+  __syncthreads();
+
+  // ---- edge ids = prefix count of creating ports; cell offsets = prefix sum of their lengths
+  int n_edges = 0, n_cells = 0;
+  for (int base = 0; base < n_ports; base += 256) {
+    int p = base + tid;
+    bool creates = false;
+    int len = 0;
+    if (p < n_ports) {
+      int q = p_end[p];
+      creates = q >= 0 && p_first[q] == p;
+      len = creates ? p_len[p] : 0;
+    }
+    int tot_e, tot_c;
+    int id = n_edges + block_flag_scan256(creates, scratch, &tot_e);
+    int off = n_cells + block_int_scan256(len, scratch, &tot_c);
+    if (creates && id < capR) {
+      int q = p_end[p];
+      int32_t* ei = edge_info + id * 5;
+      ei[0] = p >> 2;
+      ei[1] = p & 3;
+      ei[2] = q >> 2;
+      ei[3] = q & 3;
+      ei[4] = len;
+      edge_cell_off[id] = off;
+      int room = capC - off;
+      walk_rail<true>(grid, node_id, H, W, node_cell[p >> 2], p & 3, edge_cells + off, room < 0 ? 0 : room, cell_rail, id);
+    }
+    n_edges += tot_e;
+    n_cells += tot_c;
+  }
+  if (n_edges > capR) err |= FLM_GRAPH_ERR_RAILS;
+  if (n_cells > capC) err |= FLM_GRAPH_ERR_CELLS;
+  if (tid == 0) {
+    if (n_edges <= capR) edge_cell_off[n_edges] = n_cells;
+    counts[0] = n_nodes;
+    counts[1] = n_edges;
+    counts[2] = n_cells;
+    counts[3] = err;
+  }
+}
+
+// Compact numbering of rail cells + reverse-move table, one workgroup per environment.
+__global__ __launch_bounds__(256) void state_index_kernel(const uint16_t* __restrict__ grid_all, int H, int W, int capCells,
+                                                          int32_t* __restrict__ cell_idx_all, int32_t* __restrict__ n_cells_all,
+                                                          uint16_t* __restrict__ pred_all, int32_t* __restrict__ counts_all) {
+  __shared__ int scratch[8];
+  const int e = blockIdx.x, tid = threadIdx.x, HW = H * W;
+  const uint16_t* grid = grid_all + (size_t)e * HW;
+  int32_t* cell_idx = cell_idx_all + (size_t)e * HW;
+  uint16_t* pred = pred_all + (size_t)e * capCells * 16;
+  int n = 0;
+  for (int base = 0; base < HW; base += 256) {
+    int cell = base + tid;
+    bool rail = cell < HW && grid[cell] != 0;
+    int tot;
+    int id = n + block_flag_scan256(rail, scratch, &tot);
+    if (cell < HW) cell_idx[cell] = (rail && id < capCells) ? id : -1;
+    n += tot;
+  }
+  if (tid == 0) {
+    n_cells_all[e] = n > capCells ? capCells : n;
+    if (n > capCells) atomicOr(&counts_all[e * 4 + 3], FLM_GRAPH_ERR_STATES);
+  }
+  __syncthreads();
+  // state (cell, h) is reached in one move from (cell - move(h), o) for every o allowed to leave towards h
+  for (int cell = tid; cell < HW; cell += 256) {
+    int idx = cell_idx[cell];
+    if (idx < 0) continue;
+    int r = cell / W, c = cell - r * W;
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+      uint16_t out[4] = {0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF};
+      int pr = r - dr(h), pc = c - dc(h);
+      if (pr >= 0 && pr < H && pc >= 0 && pc < W) {
+        int pcell = pr * W + pc;
+        int pidx = cell_idx[pcell];
+        unsigned code = grid[pcell];
+        if (pidx >= 0) {
+          int k = 0;
+#pragma unroll
+          for (int o = 0; o < 4; o++)
+            if (has_exit(nibble(code, o), h)) out[k++] = (uint16_t)(pidx * 4 + o);
+        }
+      }
+      ushort4 v = make_ushort4(out[0], out[1], out[2], out[3]);
+      reinterpret_cast<ushort4*>(pred)[idx * 4 + h] = v;
+    }
+  }
+}
+
+}  // namespace flm
+
+extern "C" int flm_graph_build(const uint16_t* grid, int E, int H, int W, int capN, int capR, int capC,
+                               int32_t* node_id, int32_t* node_cell, int32_t* edge_info, int32_t* edge_cell_off,
+                               int32_t* edge_cells, int32_t* cell_rail, int32_t* counts, void* stream) {
+  if (!grid || !node_id || !node_cell || !edge_info || !edge_cell_off || !edge_cells || !cell_rail || !counts)
+    return FLM_E_ARG;
+  if (E <= 0 || H <= 0 || W <= 0 || capN <= 0 || capN > FLM_MAX_NODES || capR <= 0 || capC <= 0) return FLM_E_ARG;
+  size_t lds = sizeof(int) * (8 + (size_t)capN * 13);
+  hipLaunchKernelGGL(flm::graph_build_kernel, dim3(E), dim3(256), lds, (hipStream_t)stream, grid, H, W, capN, capR,
+                     capC, node_id, node_cell, edge_info, edge_cell_off, edge_cells, cell_rail, counts);
+  FLM_CHECK_LAUNCH();
+  return FLM_OK;
+}
+
+extern "C" int flm_state_index(const uint16_t* grid, int E, int H, int W, int capCells, int32_t* cell_idx,
+                               int32_t* n_cells, uint16_t* pred, int32_t* counts, void* stream) {
+  if (!grid || !cell_idx || !n_cells || !pred || !counts) return FLM_E_ARG;
+  if (E <= 0 || H <= 0 || W <= 0 || capCells <= 0 || capCells * 4 >= 65535) return FLM_E_ARG;
+  hipLaunchKernelGGL(flm::state_index_kernel, dim3(E), dim3(256), 0, (hipStream_t)stream, grid, H, W, capCells,
+                     cell_idx, n_cells, pred, counts);
+  FLM_CHECK_LAUNCH();
+  return FLM_OK;
+}

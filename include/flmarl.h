@@ -1,0 +1,128 @@
+/*
+ * flmarl.h — C ABI of the MI355X (gfx950) observation hot path of flatland-marl.
+ *
+ * Every entry point takes plain device pointers, sizes and a HIP stream
+ * (hipStream_t passed as void*), launches asynchronously on that stream and
+ * returns 0 on success or a negative FLM_E_* code.  No entry point allocates
+ * device memory or keeps state between calls.  One "batch" is E independent
+ * environments of identical grid size H x W with A agents each.
+ *
+ * Encodings shared by all calls
+ *   heading        0..3 = N,E,S,W; a cell is r*W + c
+ *   grid           uint16 transition code per cell: four nibbles, the most
+ *                  significant one for an agent heading N, then E,S,W; inside a
+ *                  nibble the most significant bit allows leaving towards N
+ *   status         0 READY_TO_DEPART, 1 ACTIVE, 2 DONE, 3 DONE_REMOVED
+ *   occupancy      int8 in {-1,0,+1}; -1 = travelling the rail from its source
+ *                  node to its destination node, +1 the other way
+ *   plane          one agent's [Rp, T1] int8 rows (rail-major), stored with a
+ *                  stride of plane_stride bytes, plane_stride % 16 == 0 and
+ *                  plane_stride >= Rp*T1; bytes past Rp*T1 are zero
+ *   per-agent err  0 ok, FLM_AGENT_* when the reference would raise
+ *
+ * Reference = misterdev/flatland-marl; file:line below are relative to its root.
+ */
+#ifndef FLMARL_H
+#define FLMARL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLM_OK 0
+#define FLM_E_ARG (-1)      /* bad size, null pointer, unsupported capacity */
+#define FLM_E_LAUNCH (-2)   /* the HIP runtime refused a launch or a memset */
+
+#define FLM_AGENT_OK 0
+#define FLM_AGENT_INDEX_ERROR 2   /* src/rail_observations.py:350, :367 */
+#define FLM_AGENT_KEY_ERROR 3     /* src/rail_observations.py:353, :365, :382 */
+#define FLM_AGENT_ASSERT_ERROR 4  /* src/rail_observations.py:395; src/utils/shortest_path.py:108, :125 */
+#define FLM_AGENT_OVERFLOW 5      /* more alternatives / longer path than the caller's capacity */
+
+#define FLM_GRAPH_ERR_NODES 1     /* counts[3] bits: capacity exceeded */
+#define FLM_GRAPH_ERR_RAILS 2
+#define FLM_GRAPH_ERR_CELLS 4
+#define FLM_GRAPH_ERR_STATES 8
+
+#define FLM_DIST_INF 0xFFFFu
+#define FLM_MAX_NODES 2048        /* per environment (LDS-resident port tables) */
+
+int flm_abi_version(void);
+
+/* Switch graph of each grid.
+ * Replaces RailObsForRailEnv._map_to_graph, src/rail_observations.py:410-510, and the cell->rail
+ * lookup _get_edge_from_cell, src/rail_observations.py:311-321.
+ *   grid          [E,H,W] uint16
+ *   node_id       [E,H*W] int32   id of the switch/diamond in the cell, -1 otherwise (row-major numbering)
+ *   node_cell     [E,capN] int32
+ *   edge_info     [E,capR,5] int32  source node, source cardinal point, destination node, destination
+ *                                   cardinal point, number of cells between them
+ *   edge_cell_off [E,capR+1] int32, edge_cells [E,capC] int32 = cell*4 + heading, in walk order
+ *   cell_rail     [E,H*W] int32   lowest rail id whose cell list holds the cell, -1 if none
+ *   counts        [E,4] int32     nodes, rails, edge cells, FLM_GRAPH_ERR_* bits
+ * capN <= FLM_MAX_NODES. */
+int flm_graph_build(const uint16_t* grid, int E, int H, int W, int capN, int capR, int capC,
+                    int32_t* node_id, int32_t* node_cell, int32_t* edge_info, int32_t* edge_cell_off,
+                    int32_t* edge_cells, int32_t* cell_rail, int32_t* counts, void* stream);
+
+/* Compact numbering of the rail cells of each grid and the reverse-move table the distance BFS walks.
+ * No reference counterpart of its own: it prepares flatland's DistanceMap computation used at
+ * src/utils/shortest_path.py:60-62.
+ *   cell_idx [E,H*W] int32 (-1 = empty cell), n_cells [E] int32,
+ *   pred     [E,capCells*4,4] uint16: for state cell_idx*4+heading, the states that reach it in one move
+ *            (0xFFFF = none).  capCells*4 < 65535.  counts[e*4+3] gets FLM_GRAPH_ERR_STATES on overflow. */
+int flm_state_index(const uint16_t* grid, int E, int H, int W, int capCells, int32_t* cell_idx,
+                    int32_t* n_cells, uint16_t* pred, int32_t* counts, void* stream);
+
+/* Distance of every (cell, heading) state to each agent's target, one BFS per distinct target.
+ * Replaces flatland DistanceMap.get() as called at src/utils/shortest_path.py:60-62.
+ *   target_cell [E,A] int32
+ *   tslot       [E,A] int32 out: row of dist that holds the agent's target
+ *   n_slots     [E] int32 out, slot_target [E,A] int32 out (target cell of each used row)
+ *   dist        [E,A,capCells*4] uint16 out, FLM_DIST_INF = unreachable */
+int flm_distance_bfs(const uint16_t* pred, const int32_t* cell_idx, const int32_t* n_cells,
+                     const int32_t* target_cell, int E, int A, int H, int W, int capCells, int32_t* tslot,
+                     int32_t* n_slots, int32_t* slot_target, uint16_t* dist, void* stream);
+
+/* Greedy descent on the distance map, ties broken left, forward, right.
+ * Replaces get_shortest_paths, src/utils/shortest_path.py:11-90.
+ *   start_cell/start_dir [E,A] int32: the position chosen at :38-49; status [E,A] int32
+ *   path_cell [E,A,Lcap] int32, path_meta [E,A,Lcap] uint32 = heading | action<<8 | next heading<<16
+ *   (next cell = cell + move(next heading), or the same cell when action == 4)
+ *   path_len  [E,A] int32, -1 = None.  Lcap >= max_depth + 1. */
+int flm_shortest_paths(const uint16_t* grid, const int32_t* cell_idx, const uint16_t* dist,
+                       const int32_t* tslot, const int32_t* start_cell, const int32_t* start_dir,
+                       const int32_t* target_cell, const int32_t* status, int E, int A, int H, int W,
+                       int capCells, int max_depth, int Lcap, int32_t* path_cell, uint32_t* path_meta,
+                       int32_t* path_len, void* stream);
+
+/* Path -> predicted cell per time step -> rail-occupancy plane, optionally moved one step to the right.
+ * Replaces prediction_from_path + cells_seq_from_prediction, src/predictions.py:85-143,
+ * _bitmap_from_cells_seq, src/rail_observations.py:323-407, and the shift of get_many
+ * (src/rail_observations.py:92-93) / get_altmaps (:105-107).
+ *   n_paths paths per environment: path_* are [E,n_paths,Lcap]; agent_of [E,n_paths] int32 gives the
+ *   agent each path belongs to (NULL = identity, n_paths == A); pos_cell [E,A] the agent's virtual
+ *   position; tpc [E,A] time steps per cell; planes [E,n_paths,plane_stride] int8 out;
+ *   err [E,n_paths] int32 out. */
+int flm_bitmaps(const int32_t* path_cell, const int32_t* path_len, const int32_t* agent_of,
+                const int32_t* pos_cell, const int32_t* target_cell, const int32_t* tpc,
+                const int32_t* node_id, const int32_t* cell_rail, const int32_t* edge_info, int E, int A,
+                int n_paths, int H, int W, int capR, int Rp, int T1, int plane_stride, int Lcap, int shift,
+                int8_t* planes, int32_t* err, void* stream);
+
+/* Observation of every agent: its own plane and the two heat planes "sum over the other agents" of the
+ * positive and of the negative entries.
+ * Replaces ObsPreprocessor._get_heatmap/_fill_padding/get_obs, src/preprocessing.py:8-30, 61-74
+ * (without rail reordering) for all agents of all environments in one pass.
+ *   maps [E,A,plane_stride] int8; own (may be NULL = maps) the plane shown as the agent's own
+ *   obs  [E,A,3,plane_stride] uint8 out: own plane (int8 bit pattern), positive heat, negative heat.
+ * A <= 255. */
+int flm_observations(const int8_t* maps, const int8_t* own, int E, int A, int plane_stride, uint8_t* obs,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

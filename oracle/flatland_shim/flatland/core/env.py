@@ -1,0 +1,2 @@
+"""Part of the test-only flatland stand-in; see flatland/_impl.py."""
+from flatland._impl import Environment  # noqa: F401

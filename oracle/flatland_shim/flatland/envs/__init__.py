@@ -1,0 +1,1 @@
+"""Part of the test-only flatland stand-in; see flatland/_impl.py."""

@@ -1,0 +1,142 @@
+"""HIP path vs the CPU checker and the committed goldens, through the C ABI (needs an MI355X)."""
+import numpy as np
+import pytest
+
+from tests.golden_util import env_names, load_env, load_golden, dense_from_runs, sha, path_rows_of
+
+pytestmark = pytest.mark.gpu
+
+ERR = {"IndexError": 2, "KeyError": 3, "AssertionError": 4}
+
+
+def _batch(fx, depth, **kw):
+    import flatland_marl_amd as fm
+    return fm.ObservationBatch(fx["grid"], fx["initial_position"], fx["direction"], fx["target"], fx["speed"], depth, **kw)
+
+
+@pytest.mark.parametrize("name", env_names())
+def test_graph_tables(name):
+    from oracle import oracle as orc
+    fx = load_env(name)
+    b = _batch(fx, 150).build_graph()
+    g = orc.Graph(fx["grid"])
+    assert int(b.num_nodes[0]) == g.N and int(b.R[0]) == g.R
+    assert np.array_equal(b.node_id[0].cpu().numpy(), g.node_id)
+    assert np.array_equal(b.node_cell[0, :g.N].cpu().numpy(), g.node_cell)
+    assert np.array_equal(b.edge_info[0, :g.R].cpu().numpy(), g.edge_info)
+    assert np.array_equal(b.edge_cell_off[0, :g.R + 1].cpu().numpy(), g.edge_cell_off)
+    assert np.array_equal(b.edge_cells[0, :g.edge_cells.shape[0]].cpu().numpy(), g.edge_cells)
+    assert np.array_equal(b.cell_rail[0].cpu().numpy(), g.cell_rail)
+
+
+@pytest.mark.parametrize("name", env_names())
+def test_distances_paths_maps_obs(name):
+    from oracle import oracle as orc
+    depth = 150
+    fx, gold = load_env(name), load_golden(name, depth)
+    b = _batch(fx, depth)
+    b.reset()
+    env = orc.OracleEnv(fx, depth)
+    # distances: compact uint16 -> dense int32, against the checker (and the golden hash)
+    cell_idx = b.cell_idx[0].cpu().numpy()
+    dist = b.dist[0].cpu().numpy().view(np.uint16)
+    tslot = b.tslot[0].cpu().numpy()
+    rail = cell_idx >= 0
+    dense = np.full((env.A, env.H * env.W, 4), -1, np.int32)
+    for a in range(env.A):
+        d = dist[tslot[a]].reshape(-1, 4)[cell_idx[rail]].astype(np.int32)
+        d[d == 0xFFFF] = -1
+        dense[a, rail] = d
+    dense = dense.reshape(env.A, env.H, env.W, 4)
+    for a in range(env.A):
+        assert np.array_equal(dense[a], env.dist(a)), (name, a)
+    assert sha(dense) == str(gold["dist_sha"])
+    # shortest paths against the golden (reference output)
+    paths = b.paths_numpy(0)
+    for a in range(env.A):
+        if gold["path_none"][a]:
+            assert paths[a] is None
+        else:
+            assert np.array_equal(paths[a], path_rows_of(gold, a)), (name, a)
+    # occupancy planes
+    err = b.agent_err[0].cpu().numpy()
+    gerr = str(gold["error"])
+    omaps, _, oerrs = env.get_many()
+    assert [ERR.get(x, 0) for x in oerrs] == list(err)
+    if gerr:
+        first = [x for x in err if x][0]
+        assert first == ERR[gerr]
+        return
+    want = dense_from_runs(gold["maps_runs"], tuple(gold["maps_shape"]))
+    got = b.maps_numpy(0)
+    assert np.array_equal(got, want)
+    assert sha(got) == str(gold["maps_sha"])
+    # padded rows and the tail of each plane stay zero
+    full = b.maps[0].cpu().numpy()
+    assert not full[:, int(b.R[0]) * b.T1:].any()
+
+
+@pytest.mark.parametrize("name", [n for n in env_names() if not n.startswith("Test_6")])
+def test_observations_golden(name):
+    import hashlib
+    depth = 150
+    fx, gold = load_env(name), load_golden(name, depth)
+    Rp = int(gold["obs_rp"])
+    b = _batch(fx, depth, max_rails=Rp)
+    b.reset()
+    b.observations()
+    obs = b.obs_numpy(0)
+    assert obs.shape == (b.A, 3, Rp, depth + 1)
+    h = hashlib.sha256()
+    for a in range(b.A):
+        h.update(obs[a].tobytes())
+    assert h.hexdigest() == str(gold["obs_sha"])
+    for i, a in enumerate(gold["obs_sample_agents"]):
+        w = dense_from_runs(gold["obs_sample_runs_%d" % i], (3, Rp, depth + 1), np.int16)
+        assert np.array_equal(obs[a], w)
+
+
+def test_depth300_large_map():
+    depth = 300
+    fx, gold = load_env("Test_9_Level_0"), load_golden("Test_9_Level_0", depth)
+    b = _batch(fx, depth)
+    b.reset()
+    want = dense_from_runs(gold["maps_runs"], tuple(gold["maps_shape"]))
+    assert np.array_equal(b.maps_numpy(0), want)
+    import hashlib
+    Rp = int(gold["obs_rp"])
+    b2 = _batch(fx, depth, max_rails=Rp)
+    b2.reset()
+    b2.observations()
+    obs = b2.obs_numpy(0)
+    h = hashlib.sha256()
+    for a in range(b2.A):
+        h.update(obs[a].tobytes())
+    assert h.hexdigest() == str(gold["obs_sha"])
+
+
+def test_batched_envs_match_single():
+    """E > 1: every environment of a batch equals the same environment run alone (agents permuted per env)."""
+    from oracle import oracle as orc
+    depth = 150
+    fx = load_env("Test_2_Level_0")
+    E, A = 5, 80
+    rng = np.random.default_rng(0)
+    perms = [rng.permutation(A) for _ in range(E)]
+    import flatland_marl_amd as fm
+    grid = np.stack([fx["grid"]] * E)
+    b = fm.ObservationBatch(grid, np.stack([fx["initial_position"][p] for p in perms]),
+                            np.stack([fx["direction"][p] for p in perms]),
+                            np.stack([fx["target"][p] for p in perms]),
+                            np.stack([fx["speed"][p] for p in perms]), depth, max_rails=100)
+    b.reset()
+    b.observations()
+    env = orc.OracleEnv(fx, depth)
+    maps, _, errs = env.get_many()
+    for e in range(E):
+        got = b.maps_numpy(e)
+        assert np.array_equal(got, maps[perms[e]])
+        obs = b.obs_numpy(e)
+        for a in (0, 17, 79):
+            want = orc.get_obs(maps[perms[e]], a, maps[perms[e]][a], 100).reshape(3, 100, depth + 1)
+            assert np.array_equal(obs[a], want)
