@@ -1,0 +1,171 @@
+"""Throughput of the observation hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg5] [--envs E]
+
+One step = one pass of the whole path over one resident batch of environments:
+switch-graph build -> state numbering -> distance BFS per distinct target ->
+greedy shortest paths -> occupancy planes -> observations (own plane + two heat
+planes for every agent).  Inputs (grids, agent states) are in HBM before the
+timed region; nothing is copied to the host inside it.  With N > 1 every rank
+runs its own shard of environments (no collective on the data path), so the
+scaling is weak: per-GPU work is fixed.
+
+Prints one JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (fixtures, envs per GPU, agents, depth, description)
+    "cfg3": (["Test_8_Level_0", "Test_8_Level_1"], 4096, 50, 150,
+             "4096 envs x 50 agents, 100x100 grid (Test_8-class maps, 8 symmetries x 2 levels, agents re-drawn), depth 150"),
+    "cfg5": (["Test_9_Level_0", "Test_9_Level_1"], 256, 200, 300,
+             "256 envs x 200 agents, 150x150 grid (Test_9-class maps), depth 300"),
+    "cfg2": (["Test_2_Level_0", "Test_2_Level_1"], 1024, 10, 150,
+             "1024 envs x 10 agents, 35x35 grid (Test_2-class maps stand in for 25x25), max_rails 70+, depth 150"),
+}
+
+
+def load_fixtures(names):
+    return [dict(np.load(os.path.join(ROOT, "tests", "golden", "envs", n + ".npz"))) for n in names]
+
+
+def cpu_baseline(data, depth, Rp, budget_s=12.0, max_envs=64):
+    """The CPU checker (a C restatement of the reference algorithm, one thread) on the first few
+    environments of the same batch: graph + distance maps + paths + planes + get_obs for every agent."""
+    from oracle import oracle as orc
+    orc.lib()
+    t0 = time.perf_counter()
+    n_env = 0
+    n_obs = 0
+    E, A = data["start"].shape[:2]
+    while n_env < min(E, max_envs) and (time.perf_counter() - t0) < budget_s:
+        e = n_env
+        fx = dict(grid=data["grid"][e], initial_position=data["start"][e], direction=data["direction"][e],
+                  target=data["target"][e], speed=data["speed"][e], handle=np.arange(A))
+        env = orc.OracleEnv(fx, depth)
+        maps, _, _ = env.get_many()
+        for a in range(A):
+            orc.get_obs(maps, a, maps[a], Rp)
+        n_env += 1
+        n_obs += A
+    dt = time.perf_counter() - t0
+    return dict(value=n_obs / dt, unit="agent-observations/s", cores=1, kind="port",
+                sample="%d environments (%d agent-observations) of the same batch in %.1f s, single thread, "
+                       "C restatement of the reference algorithm (oracle/flmarl_oracle.c)" % (n_env, n_obs, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--envs", type=int, default=0, help="environments per GPU (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(device)
+
+    import flatland_marl_amd as fm
+    from flatland_marl_amd.synthetic import make_batch
+
+    names, E, A, depth, desc = WORKLOADS[args.workload]
+    if args.envs:
+        E = args.envs
+    data = make_batch(load_fixtures(names), E, A, seed=1000003 * rank)
+    batch = fm.ObservationBatch(data["grid"], data["start"], data["direction"], data["target"], data["speed"], depth,
+                                device=device)
+    batch.reset(sync=True)          # sizes the rail axis (one host read-back), allocates every buffer
+    batch.observations()
+    Rp, T1 = batch.Rp, batch.T1
+
+    def step(ev=None):
+        batch.reset(sync=False)
+        if ev is not None:
+            ev[0].record()
+        batch.observations()
+        if ev is not None:
+            ev[1].record()
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    barrier()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    batch.check_graph()
+    n_err = int((batch.agent_err != 0).sum().item())
+    obs_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+
+    if rank == 0:
+        total_obs = E * A * world * args.steps
+        alg_bytes = 4.0 * Rp * T1 * E * A          # per launch of the observation kernel
+        achieved = alg_bytes / (obs_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "obs_kernel_traffic_%s.json" % args.workload)
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "agent-observations/sec (bitmap+heatmaps)",
+            "value": total_obs / dt,
+            "unit": "agent-observations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "i8",
+            "data": "synthetic",
+            "config": {"workload": "%s: %s" % (args.workload, desc), "envs_per_gpu": E, "agents": A,
+                       "rails_padded": int(Rp), "depth": depth, "agents_flagged": n_err,
+                       "step": "graph build + distance BFS + shortest paths + occupancy planes + observations"},
+            "roofline": {"kernel": "observations_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
+                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": obs_ms},
+            "observations_only": {"value": E * A / (obs_ms * 1e-3), "unit": "agent-observations/s",
+                                  "note": "heat/observation sweep alone, one GPU"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(data, depth, int(Rp))
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,37 +67,55 @@ class ObservationBatch:
         self.stream = torch.cuda.current_stream(self.device)
 
     # ------------------------------------------------------------------ graph
-    def build_graph(self):
-        """Switch graph + cell->rail table (+ state numbering for the BFS)."""
-        E, H, W, dev = self.E, self.H, self.W, self.device
-        HW = H * W
-        capN = min(_lib.MAX_NODES, self.cap_cells)
-        capR = 2 * capN + 8
-        capC = 2 * self.cap_cells + 2 * (H + W)
+    def _alloc_graph(self, capN, capR, capC):
+        E, HW, dev = self.E, self.H * self.W, self.device
         i32 = dict(dtype=torch.int32, device=dev)
+        self.capN, self.capR, self.capC = capN, capR, capC
+        self.node_id = torch.empty((E, HW), **i32)
+        self.node_cell = torch.empty((E, capN), **i32)
+        self.edge_info = torch.empty((E, capR, 5), **i32)
+        self.edge_cell_off = torch.empty((E, capR + 1), **i32)
+        self.edge_cells = torch.empty((E, capC), **i32)
+        self.cell_rail = torch.empty((E, HW), **i32)
+        self.counts = torch.zeros((E, 4), **i32)
+        self.cell_idx = torch.empty((E, HW), **i32)
+        self.n_cells = torch.empty((E,), **i32)
+        self.pred = torch.empty((E, self.cap_cells * 4, 4), dtype=torch.int16, device=dev)
+
+    def _launch_graph(self):
+        E, H, W = self.E, self.H, self.W
+        s = self.stream.cuda_stream
+        call("flm_graph_build", ptr(self.grid), E, H, W, self.capN, self.capR, self.capC, ptr(self.node_id),
+             ptr(self.node_cell), ptr(self.edge_info), ptr(self.edge_cell_off), ptr(self.edge_cells),
+             ptr(self.cell_rail), ptr(self.counts), s)
+        call("flm_state_index", ptr(self.grid), E, H, W, self.cap_cells, ptr(self.cell_idx), ptr(self.n_cells),
+             ptr(self.pred), ptr(self.counts), s)
+
+    def build_graph(self, sync=True):
+        """Switch graph + cell->rail table + state numbering for the BFS.
+
+        sync=True reads the per-environment counts back (sizes the rail axis, grows capacities, raises on
+        overflow).  sync=False only enqueues the kernels into buffers sized by an earlier synchronous call;
+        check_graph() validates afterwards."""
+        if not sync:
+            if self.R is None:
+                raise _lib.FlmError("build_graph(sync=False) needs one synchronous call first")
+            self._launch_graph()
+            return self
+        if getattr(self, "capN", None) is None:
+            capN = min(_lib.MAX_NODES, self.cap_cells)
+            self._alloc_graph(capN, 2 * capN + 8, 2 * self.cap_cells + 2 * (self.H + self.W))
         for attempt in range(3):
-            self.node_id = torch.empty((E, HW), **i32)
-            self.node_cell = torch.empty((E, capN), **i32)
-            self.edge_info = torch.empty((E, capR, 5), **i32)
-            self.edge_cell_off = torch.empty((E, capR + 1), **i32)
-            self.edge_cells = torch.empty((E, capC), **i32)
-            self.cell_rail = torch.empty((E, HW), **i32)
-            self.counts = torch.zeros((E, 4), **i32)
-            s = self.stream.cuda_stream
-            call("flm_graph_build", ptr(self.grid), E, H, W, capN, capR, capC, ptr(self.node_id), ptr(self.node_cell),
-                 ptr(self.edge_info), ptr(self.edge_cell_off), ptr(self.edge_cells), ptr(self.cell_rail),
-                 ptr(self.counts), s)
+            self._launch_graph()
             counts = self.counts.cpu().numpy()
             errs = int(np.bitwise_or.reduce(counts[:, 3]))
             if errs == 0:
                 break
             if errs & _lib.GRAPH_ERR_NODES:
                 raise ValueError("more than %d switches in one environment" % _lib.MAX_NODES)
-            capR = max(capR, int(counts[:, 1].max()))
-            capC = max(capC, int(counts[:, 2].max()))
+            self._alloc_graph(self.capN, max(self.capR, int(counts[:, 1].max())), max(self.capC, int(counts[:, 2].max())))
         else:
             raise _lib.FlmError("graph build did not converge")
-        self.capN, self.capR, self.capC = capN, capR, capC
         self.num_nodes = counts[:, 0].copy()
         self.R = counts[:, 1].copy()
         need = int(self.R.max())
@@ -106,21 +124,23 @@ class ObservationBatch:
             raise ValueError("could not broadcast: an environment has %d rails > max_rails=%d" % (need, self.max_rails))
         self.Rp = max(need, 1) if self.max_rails is None else int(self.max_rails)
         self.plane_stride = (self.Rp * self.T1 + 15) // 16 * 16
-        self.cell_idx = torch.empty((E, HW), **i32)
-        self.n_cells = torch.empty((E,), **i32)
-        self.pred = torch.empty((E, self.cap_cells * 4, 4), dtype=torch.int16, device=dev)
-        call("flm_state_index", ptr(self.grid), E, H, W, self.cap_cells, ptr(self.cell_idx), ptr(self.n_cells),
-             ptr(self.pred), ptr(self.counts), self.stream.cuda_stream)
         return self
+
+    def check_graph(self):
+        """Raise if any asynchronous build_graph since the last check overflowed or changed the rail counts."""
+        counts = self.counts.cpu().numpy()
+        if int(np.bitwise_or.reduce(counts[:, 3])) != 0 or int(counts[:, 1].max()) > self.Rp:
+            raise _lib.FlmError("graph capacities exceeded in an asynchronous build")
 
     # ------------------------------------------------------------------ distances and paths
     def compute_distances(self):
         E, A, dev = self.E, self.A, self.device
         i32 = dict(dtype=torch.int32, device=dev)
-        self.tslot = torch.empty((E, A), **i32)
-        self.n_slots = torch.empty((E,), **i32)
-        self.slot_target = torch.empty((E, A), **i32)
-        self.dist = torch.empty((E, A, self.cap_cells * 4), dtype=torch.int16, device=dev)
+        if getattr(self, "dist", None) is None:
+            self.tslot = torch.empty((E, A), **i32)
+            self.n_slots = torch.empty((E,), **i32)
+            self.slot_target = torch.empty((E, A), **i32)
+            self.dist = torch.empty((E, A, self.cap_cells * 4), dtype=torch.int16, device=dev)
         call("flm_distance_bfs", ptr(self.pred), ptr(self.cell_idx), ptr(self.n_cells), ptr(self.target_cell), E, A,
              self.H, self.W, self.cap_cells, ptr(self.tslot), ptr(self.n_slots), ptr(self.slot_target), ptr(self.dist),
              self.stream.cuda_stream)
@@ -131,9 +151,12 @@ class ObservationBatch:
         E, A, dev = self.E, self.A, self.device
         max_depth = self.T1 if max_depth is None else int(max_depth)
         Lcap = max_depth + 1
-        path_cell = torch.empty((E, A, Lcap), dtype=torch.int32, device=dev)
-        path_meta = torch.empty((E, A, Lcap), dtype=torch.int32, device=dev)
-        path_len = torch.empty((E, A), dtype=torch.int32, device=dev)
+        if getattr(self, "Lcap", None) == Lcap:
+            path_cell, path_meta, path_len = self.path_cell, self.path_meta, self.path_len
+        else:
+            path_cell = torch.empty((E, A, Lcap), dtype=torch.int32, device=dev)
+            path_meta = torch.empty((E, A, Lcap), dtype=torch.int32, device=dev)
+            path_len = torch.empty((E, A), dtype=torch.int32, device=dev)
         sc = self.pos_cell if start_cell is None else start_cell
         sd = self.direction if start_dir is None else start_dir
         call("flm_shortest_paths", ptr(self.grid), ptr(self.cell_idx), ptr(self.dist), ptr(self.tslot), ptr(sc),
@@ -147,8 +170,11 @@ class ObservationBatch:
         """Occupancy planes of the current paths; shift=1 is get_many (src/rail_observations.py:78-95)."""
         E, A, dev = self.E, self.A, self.device
         if out is None:
-            out = torch.empty((E, A, self.plane_stride), dtype=torch.int8, device=dev)
-        self.agent_err = torch.empty((E, A), dtype=torch.int32, device=dev)
+            shape = (E, A, self.plane_stride)
+            out = self.maps if (self.maps is not None and tuple(self.maps.shape) == shape) else \
+                torch.empty(shape, dtype=torch.int8, device=dev)
+        if getattr(self, "agent_err", None) is None:
+            self.agent_err = torch.empty((E, A), dtype=torch.int32, device=dev)
         call("flm_bitmaps", ptr(self.path_cell), ptr(self.path_len), None, ptr(self.pos_cell), ptr(self.target_cell),
              ptr(self.tpc), ptr(self.node_id), ptr(self.cell_rail), ptr(self.edge_info), E, A, A, self.H, self.W,
              self.capR, self.Rp, self.T1, self.plane_stride, self.Lcap, int(shift), ptr(out), ptr(self.agent_err),
@@ -162,18 +188,20 @@ class ObservationBatch:
         if self.A > 255:
             raise ValueError("heat counts are stored in 8 bits: at most 255 agents per environment")
         if out is None:
-            out = torch.empty((self.E, self.A, 3, self.plane_stride), dtype=torch.uint8, device=self.device)
+            shape = (self.E, self.A, 3, self.plane_stride)
+            out = self.obs if (self.obs is not None and tuple(self.obs.shape) == shape) else \
+                torch.empty(shape, dtype=torch.uint8, device=self.device)
         call("flm_observations", ptr(maps), ptr(own), self.E, self.A, self.plane_stride, ptr(out),
              self.stream.cuda_stream)
         self.obs = out
         return out
 
-    def reset(self):
+    def reset(self, sync=True, out=None):
         """Graph, distances, shortest paths, occupancy planes: what env.reset() triggers in the reference."""
-        self.build_graph()
+        self.build_graph(sync=sync)
         self.compute_distances()
         self.shortest_paths()
-        return self.bitmaps(shift=1)
+        return self.bitmaps(shift=1, out=out)
 
     # ------------------------------------------------------------------ host views (tests, drop-in classes)
     def maps_numpy(self, e=0, maps=None):
