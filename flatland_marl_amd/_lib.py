@@ -26,6 +26,7 @@ _SIGNATURES = {
     "flm_shortest_paths": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     "flm_bitmaps": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     "flm_observations": [_p, _p, _i, _i, _i, _p, _p],
+    "flm_dev_set_option": [_i, _i],
 }
 
 _lib = None

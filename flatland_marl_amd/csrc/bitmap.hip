@@ -154,47 +154,79 @@ __device__ __forceinline__ uint4 neg_bits4(uint4 v) { return make_uint4(neg_bits
 __device__ __forceinline__ uint4 add4(uint4 a, uint4 b) { return make_uint4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ uint4 sub4(uint4 a, uint4 b) { return make_uint4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
-template <int APW>
+template <bool NT>
+__device__ __forceinline__ void store16(uint8_t* p, uint4 v) {
+  typedef unsigned vec4u __attribute__((ext_vector_type(4)));
+  if (NT) {
+    vec4u t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<vec4u*>(p));
+  } else {
+    *reinterpret_cast<uint4*>(p) = v;
+  }
+}
+
+// APW = agents per wave, CH = 1-KiB chunks per workgroup (each lane owns CH pieces of 16 bytes),
+// NT = non-temporal stores for the write-once output.
+template <int APW, int CH, bool NT>
 __global__ __launch_bounds__(1024) void observations_kernel(const int8_t* __restrict__ maps, const int8_t* __restrict__ own,
                                                             int A, int plane_stride, uint8_t* __restrict__ obs) {
-  extern __shared__ __attribute__((aligned(16))) uint4 part[];  // [nw][2][64]
+  extern __shared__ __attribute__((aligned(16))) uint4 part[];  // [nw][2*CH][64]
   const int nw = blockDim.x >> 6;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int e = blockIdx.y;
-  const size_t off = (size_t)blockIdx.x * 1024 + (size_t)lane * 16;
-  const bool active = off < (size_t)plane_stride;
+  const size_t off0 = (size_t)blockIdx.x * (1024 * CH) + (size_t)lane * 16;
   const size_t env_base = (size_t)e * A;
-  uint4 v[APW];
-  uint4 psum = make_uint4(0, 0, 0, 0), nsum = make_uint4(0, 0, 0, 0);
+  uint4 v[APW][CH];
+  uint4 psum[CH], nsum[CH];
+#pragma unroll
+  for (int c = 0; c < CH; c++) psum[c] = nsum[c] = make_uint4(0, 0, 0, 0);
 #pragma unroll
   for (int i = 0; i < APW; i++) {
     int a = wave + i * nw;
-    v[i] = make_uint4(0, 0, 0, 0);
-    if (active && a < A) v[i] = *reinterpret_cast<const uint4*>(maps + (env_base + a) * plane_stride + off);
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+      size_t off = off0 + (size_t)c * 1024;
+      v[i][c] = make_uint4(0, 0, 0, 0);
+      if (off < (size_t)plane_stride && a < A)
+        v[i][c] = *reinterpret_cast<const uint4*>(maps + (env_base + a) * plane_stride + off);
+    }
   }
 #pragma unroll
-  for (int i = 0; i < APW; i++) {
-    psum = add4(psum, pos_bits4(v[i]));
-    nsum = add4(nsum, neg_bits4(v[i]));
+  for (int i = 0; i < APW; i++)
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+      psum[c] = add4(psum[c], pos_bits4(v[i][c]));
+      nsum[c] = add4(nsum[c], neg_bits4(v[i][c]));
+    }
+#pragma unroll
+  for (int c = 0; c < CH; c++) {
+    part[((wave * CH + c) * 2 + 0) * 64 + lane] = psum[c];
+    part[((wave * CH + c) * 2 + 1) * 64 + lane] = nsum[c];
   }
-  part[(wave * 2 + 0) * 64 + lane] = psum;
-  part[(wave * 2 + 1) * 64 + lane] = nsum;
   __syncthreads();
-  uint4 ptot = make_uint4(0, 0, 0, 0), ntot = make_uint4(0, 0, 0, 0);
-  for (int w = 0; w < nw; w++) {
-    ptot = add4(ptot, part[(w * 2 + 0) * 64 + lane]);
-    ntot = add4(ntot, part[(w * 2 + 1) * 64 + lane]);
-  }
+  uint4 ptot[CH], ntot[CH];
+#pragma unroll
+  for (int c = 0; c < CH; c++) ptot[c] = ntot[c] = make_uint4(0, 0, 0, 0);
+  for (int w = 0; w < nw; w++)
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+      ptot[c] = add4(ptot[c], part[((w * CH + c) * 2 + 0) * 64 + lane]);
+      ntot[c] = add4(ntot[c], part[((w * CH + c) * 2 + 1) * 64 + lane]);
+    }
 #pragma unroll
   for (int i = 0; i < APW; i++) {
     int a = wave + i * nw;
-    if (active && a < A) {
-      uint4 mine = v[i];
-      uint4 shown = own ? *reinterpret_cast<const uint4*>(own + (env_base + a) * plane_stride + off) : mine;
-      uint8_t* o = obs + (env_base + a) * 3 * plane_stride + off;
-      *reinterpret_cast<uint4*>(o) = shown;
-      *reinterpret_cast<uint4*>(o + plane_stride) = sub4(ptot, pos_bits4(mine));
-      *reinterpret_cast<uint4*>(o + 2 * (size_t)plane_stride) = sub4(ntot, neg_bits4(mine));
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+      size_t off = off0 + (size_t)c * 1024;
+      if (off < (size_t)plane_stride && a < A) {
+        uint4 mine = v[i][c];
+        uint4 shown = own ? *reinterpret_cast<const uint4*>(own + (env_base + a) * plane_stride + off) : mine;
+        uint8_t* o = obs + (env_base + a) * 3 * plane_stride + off;
+        store16<NT>(o, shown);
+        store16<NT>(o + plane_stride, sub4(ptot[c], pos_bits4(mine)));
+        store16<NT>(o + 2 * (size_t)plane_stride, sub4(ntot[c], neg_bits4(mine)));
+      }
     }
   }
 }
@@ -221,14 +253,38 @@ extern "C" int flm_bitmaps(const int32_t* path_cell, const int32_t* path_len, co
   return FLM_OK;
 }
 
-template <int APW>
+int g_flm_dev_opt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// Tuning hook for benchmarks (not part of the stable interface): key 0 = observation kernel variant.
+extern "C" int flm_dev_set_option(int key, int value) {
+  if (key < 0 || key >= 8) return FLM_E_ARG;
+  g_flm_dev_opt[key] = value;
+  return FLM_OK;
+}
+
+template <int APW, int CH, bool NT>
 static int launch_obs(const int8_t* maps, const int8_t* own, int E, int A, int plane_stride, uint8_t* obs, int nw,
                       hipStream_t stream) {
-  dim3 grid((plane_stride + 1023) / 1024, E);
-  size_t lds = sizeof(uint4) * 2 * 64 * (size_t)nw;
-  hipLaunchKernelGGL(flm::observations_kernel<APW>, grid, dim3(nw * 64), lds, stream, maps, own, A, plane_stride, obs);
+  dim3 grid((plane_stride + 1024 * CH - 1) / (1024 * CH), E);
+  size_t lds = sizeof(uint4) * 2 * 64 * (size_t)nw * CH;
+  hipLaunchKernelGGL((flm::observations_kernel<APW, CH, NT>), grid, dim3(nw * 64), lds, stream, maps, own, A,
+                     plane_stride, obs);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
+}
+
+template <int CH, bool NT>
+static int launch_obs_apw(const int8_t* maps, const int8_t* own, int E, int A, int plane_stride, uint8_t* obs, int nw,
+                          hipStream_t stream) {
+  int apw = (A + nw - 1) / nw;
+  if (apw <= 1) return launch_obs<1, CH, NT>(maps, own, E, A, plane_stride, obs, nw, stream);
+  if (apw <= 2) return launch_obs<2, CH, NT>(maps, own, E, A, plane_stride, obs, nw, stream);
+  if (apw <= 4) return launch_obs<4, CH, NT>(maps, own, E, A, plane_stride, obs, nw, stream);
+  if (apw <= 7) return launch_obs<7, CH, NT>(maps, own, E, A, plane_stride, obs, nw, stream);
+  if (CH * 13 * 4 <= 128) {
+    if (apw <= 13) return launch_obs<13, CH, NT>(maps, own, E, A, plane_stride, obs, nw, stream);
+    if (apw <= 16 && CH == 1) return launch_obs<16, 1, NT>(maps, own, E, A, plane_stride, obs, nw, stream);
+  }
+  return FLM_E_ARG;
 }
 
 extern "C" int flm_observations(const int8_t* maps, const int8_t* own, int E, int A, int plane_stride, uint8_t* obs,
@@ -236,15 +292,21 @@ extern "C" int flm_observations(const int8_t* maps, const int8_t* own, int E, in
   if (!maps || !obs) return FLM_E_ARG;
   if (E <= 0 || E > 65535 || A <= 0 || A > 255 || plane_stride <= 0 || plane_stride % 16 != 0) return FLM_E_ARG;
   hipStream_t stream = (hipStream_t)stream_;
-  int nw = A <= 64 ? 4 : (A <= 128 ? 8 : 16);
+  const int variant = g_flm_dev_opt[0];
+  // variant = nwsel + 10*chsel + 100*nt;  nwsel 0 auto, 1: 4 waves, 2: 8, 3: 16;  chsel 0: 1 chunk, 1: 2, 2: 4
+  // default: 16 waves (fewest agents per wave), non-temporal stores -- the fastest of the measured variants
+  int nwsel = variant % 10, chsel = (variant / 10) % 10, nt = variant == 0 ? 1 : (variant / 100) % 10;
+  int nw = 16;
+  if (nwsel == 1) nw = 4;
+  if (nwsel == 2) nw = 8;
+  if (nwsel == 3) nw = 16;
   if (nw > A) nw = A;
-  int apw = (A + nw - 1) / nw;
-  if (apw <= 1) return launch_obs<1>(maps, own, E, A, plane_stride, obs, nw, stream);
-  if (apw <= 2) return launch_obs<2>(maps, own, E, A, plane_stride, obs, nw, stream);
-  if (apw <= 4) return launch_obs<4>(maps, own, E, A, plane_stride, obs, nw, stream);
-  if (apw <= 8) return launch_obs<8>(maps, own, E, A, plane_stride, obs, nw, stream);
-  if (apw <= 13) return launch_obs<13>(maps, own, E, A, plane_stride, obs, nw, stream);
-  return launch_obs<16>(maps, own, E, A, plane_stride, obs, nw, stream);
+  if (chsel == 0) return nt ? launch_obs_apw<1, true>(maps, own, E, A, plane_stride, obs, nw, stream)
+                            : launch_obs_apw<1, false>(maps, own, E, A, plane_stride, obs, nw, stream);
+  if (chsel == 1) return nt ? launch_obs_apw<2, true>(maps, own, E, A, plane_stride, obs, nw, stream)
+                            : launch_obs_apw<2, false>(maps, own, E, A, plane_stride, obs, nw, stream);
+  return nt ? launch_obs_apw<4, true>(maps, own, E, A, plane_stride, obs, nw, stream)
+            : launch_obs_apw<4, false>(maps, own, E, A, plane_stride, obs, nw, stream);
 }
 
 extern "C" int flm_abi_version(void) { return 1; }

@@ -1,0 +1,51 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol the header declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "flmarl.h")).read()
+    return sorted(set(re.findall(r"^(?:int|const char\*)\s+(flm_\w+)\s*\(", text, flags=re.M)))
+
+
+def test_header_declares_symbols():
+    names = _declared()
+    assert "flm_graph_build" in names and "flm_observations" in names and len(names) >= 7
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    lib = ctypes.CDLL(os.path.join(ROOT, "flatland_marl_amd", "libflmarl_hip.so"))
+    for name in _declared():
+        assert hasattr(lib, name), name
+    assert lib.flm_abi_version() >= 1
+
+
+def test_binding_covers_header():
+    from flatland_marl_amd import _lib
+    assert set(_declared()) <= set(_lib.exported_symbols())
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import numpy as np
+    import flatland_marl_amd as fm
+    with pytest.raises(fm.FlmError):
+        fm.ObservationBatch(np.zeros((4, 4), np.uint16), [[0, 0]], [0], [[1, 1]], [1.0], 10)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "flatland_marl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("no oracle", ""), os.path.join(dirpath, f)

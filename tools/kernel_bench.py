@@ -1,0 +1,83 @@
+"""Per-kernel timings and variant sweeps on one GPU (development tool, not a test).
+
+    python tools/kernel_bench.py [--workload cfg3] [--envs E] [--obs-variants 0,100,...] [--bfs-variants 0,1]
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import flatland_marl_amd as fm  # noqa: E402
+from flatland_marl_amd import _lib  # noqa: E402
+from flatland_marl_amd.synthetic import make_batch  # noqa: E402
+
+
+def timed(fn, reps=5, warm=1):
+    for _ in range(warm):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    t = [a.elapsed_time(b) for a, b in ev]
+    return float(np.median(t)), float(np.min(t))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="cfg3")
+    ap.add_argument("--envs", type=int, default=0)
+    ap.add_argument("--obs-variants", default="0")
+    ap.add_argument("--bfs-variants", default="0")
+    ap.add_argument("--stages", default="graph,bfs,paths,bitmaps,obs")
+    args = ap.parse_args()
+    names, E, A, depth, desc = bench.WORKLOADS[args.workload]
+    E = args.envs or E
+    data = make_batch(bench.load_fixtures(names), E, A, seed=0)
+    b = fm.ObservationBatch(data["grid"], data["start"], data["direction"], data["target"], data["speed"], depth)
+    b.reset()
+    b.observations()
+    ref_maps = b.maps.clone()
+    ref_obs_sum = int(b.obs.view(torch.int64).sum().item())
+    ref_dist = b.dist.clone()
+    stages = args.stages.split(",")
+    out = {"workload": args.workload, "E": E, "A": A, "Rp": int(b.Rp), "T1": b.T1, "n_slots_mean": float(b.n_slots.float().mean())}
+    if "graph" in stages:
+        out["graph_ms"] = timed(lambda: b.build_graph(sync=False))
+    if "bfs" in stages:
+        for v in [int(x) for x in args.bfs_variants.split(",")]:
+            _lib.call("flm_dev_set_option", 1, v)
+            out["bfs_ms_v%d" % v] = timed(b.compute_distances)
+            out["bfs_equal_v%d" % v] = bool(torch.equal(b.dist, ref_dist))
+        _lib.call("flm_dev_set_option", 1, 0)
+    if "paths" in stages:
+        out["paths_ms"] = timed(b.shortest_paths)
+    if "bitmaps" in stages:
+        out["bitmaps_ms"] = timed(lambda: b.bitmaps(shift=1))
+        out["bitmaps_equal"] = bool(torch.equal(b.maps, ref_maps))
+        out["bitmaps_GBs"] = E * A * b.plane_stride / out["bitmaps_ms"][0] / 1e6
+    if "obs" in stages:
+        alg = 4.0 * b.Rp * b.T1 * E * A
+        for v in [int(x) for x in args.obs_variants.split(",")]:
+            _lib.call("flm_dev_set_option", 0, v)
+            try:
+                b.obs.zero_()
+                t = timed(b.observations)
+                ok = int(b.obs.view(torch.int64).sum().item()) == ref_obs_sum
+                out["obs_v%d" % v] = dict(ms=t, GBs=alg / t[0] / 1e6, ok=ok)
+            except _lib.FlmError as ex:
+                out["obs_v%d" % v] = str(ex)
+        _lib.call("flm_dev_set_option", 0, 0)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
