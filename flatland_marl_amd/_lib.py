@@ -26,6 +26,10 @@ _SIGNATURES = {
     "flm_shortest_paths": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     "flm_bitmaps": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     "flm_observations": [_p, _p, _i, _i, _i, _p, _p],
+    "flm_observations_req": [_p, _p, _p, _i, _i, _i, _i, _p, _p],
+    "flm_altpaths": [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
+    "flm_check_crash": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
+    "flm_update_bitmaps": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "flm_dev_set_option": [_i, _i],
 }
 

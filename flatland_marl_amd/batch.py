@@ -176,7 +176,7 @@ class ObservationBatch:
         if getattr(self, "agent_err", None) is None:
             self.agent_err = torch.empty((E, A), dtype=torch.int32, device=dev)
         call("flm_bitmaps", ptr(self.path_cell), ptr(self.path_len), None, ptr(self.pos_cell), ptr(self.target_cell),
-             ptr(self.tpc), ptr(self.node_id), ptr(self.cell_rail), ptr(self.edge_info), E, A, A, self.H, self.W,
+             ptr(self.tpc), ptr(self.node_id), ptr(self.cell_rail), ptr(self.edge_info), E, A, E * A, self.H, self.W,
              self.capR, self.Rp, self.T1, self.plane_stride, self.Lcap, int(shift), ptr(out), ptr(self.agent_err),
              self.stream.cuda_stream)
         self.maps = out
@@ -203,7 +203,88 @@ class ObservationBatch:
         self.shortest_paths()
         return self.bitmaps(shift=1, out=out)
 
+    # ------------------------------------------------------------------ rollout
+    def set_agent_state(self, status=None, pos_cell=None, direction=None):
+        """Upload the agents' current status / cell (-1 = off the grid) / heading, each [E,A]."""
+        if status is not None:
+            self.status.copy_(_dev_i32(np.asarray(status).reshape(self.E, self.A), self.device))
+        if pos_cell is not None:
+            self.pos_cell.copy_(_dev_i32(np.asarray(pos_cell).reshape(self.E, self.A), self.device))
+        if direction is not None:
+            self.direction.copy_(_dev_i32(np.asarray(direction).reshape(self.E, self.A), self.device))
+
+    def altpaths(self, req_agent, max_depth=500, cap_alt=8):
+        """get_altpaths (src/utils/shortest_path.py:92-163) for the agents e*A+a listed in req_agent."""
+        req = _dev_i32(np.asarray(req_agent).reshape(-1), self.device)
+        n = req.numel()
+        Lcap = max_depth + 40
+        dev = self.device
+        out = dict(
+            count=torch.empty((n,), dtype=torch.int32, device=dev),
+            len=torch.zeros((n, cap_alt), dtype=torch.int32, device=dev),
+            cell=torch.empty((n, cap_alt, Lcap), dtype=torch.int32, device=dev),
+            meta=torch.empty((n, cap_alt, Lcap), dtype=torch.int32, device=dev),
+            err=torch.empty((n,), dtype=torch.int32, device=dev), req=req, Lcap=Lcap, cap_alt=cap_alt)
+        call("flm_altpaths", ptr(self.grid), ptr(self.cell_idx), ptr(self.dist), ptr(self.tslot), ptr(self.node_id),
+             ptr(req), n, ptr(self.pos_cell), ptr(self.direction), ptr(self.target_cell), self.E, self.A, self.H,
+             self.W, self.cap_cells, int(max_depth), cap_alt, Lcap, ptr(out["count"]), ptr(out["len"]),
+             ptr(out["cell"]), ptr(out["meta"]), ptr(out["err"]), self.stream.cuda_stream)
+        return out
+
+    def planes_for_paths(self, path_cell, path_len, agent_flat, Lcap, shift):
+        """Occupancy planes [n,plane_stride] of arbitrary paths (alternatives) of the agents agent_flat[n]."""
+        n = agent_flat.numel()
+        planes = torch.empty((n, self.plane_stride), dtype=torch.int8, device=self.device)
+        err = torch.empty((n,), dtype=torch.int32, device=self.device)
+        call("flm_bitmaps", ptr(path_cell), ptr(path_len), ptr(agent_flat), ptr(self.pos_cell), ptr(self.target_cell),
+             ptr(self.tpc), ptr(self.node_id), ptr(self.cell_rail), ptr(self.edge_info), self.E, self.A, n, self.H,
+             self.W, self.capR, self.Rp, self.T1, self.plane_stride, int(Lcap), int(shift), ptr(planes), ptr(err),
+             self.stream.cuda_stream)
+        return planes, err
+
+    def observations_for(self, maps, req_agent, own_planes=None):
+        """[n,3,plane_stride] uint8 observations of selected agents (src/preprocessing.py:61-74)."""
+        req = req_agent if torch.is_tensor(req_agent) else _dev_i32(np.asarray(req_agent).reshape(-1), self.device)
+        n = req.numel()
+        out = torch.empty((n, 3, self.plane_stride), dtype=torch.uint8, device=self.device)
+        call("flm_observations_req", ptr(maps), ptr(req), ptr(own_planes), n, self.E, self.A, self.plane_stride,
+             ptr(out), self.stream.cuda_stream)
+        return out
+
+    def check_crash(self, maps, agent_sel, before_switch, next_cell, init_cell=None):
+        """check_crash (src/rail_observations.py:206-230) for one selected agent per environment -> [E] int32."""
+        dev = self.device
+        crash = torch.zeros((self.E,), dtype=torch.int32, device=dev)
+        init = self.start_cell if init_cell is None else init_cell
+        call("flm_check_crash", ptr(maps), ptr(self.status), ptr(self.tpc), ptr(self.pos_cell), ptr(init),
+             ptr(_dev_i32(agent_sel, dev)), ptr(_dev_i32(before_switch, dev)), ptr(_dev_i32(next_cell, dev)), self.E,
+             self.A, self.Rp, self.T1, self.plane_stride, ptr(crash), self.stream.cuda_stream)
+        return crash
+
+    def update_bitmaps(self, maps, agent_sel, before_switch):
+        """update_bitmaps (src/rail_observations.py:232-252) for one selected agent per environment, in place."""
+        dev = self.device
+        call("flm_update_bitmaps", ptr(maps), ptr(self.status), ptr(self.tpc), ptr(_dev_i32(agent_sel, dev)),
+             ptr(_dev_i32(before_switch, dev)), self.E, self.A, self.Rp, self.T1, self.plane_stride,
+             self.stream.cuda_stream)
+        return maps
+
     # ------------------------------------------------------------------ host views (tests, drop-in classes)
+    def upload_maps(self, host_maps, e=0, out=None):
+        """[A,R,T1] host array of one environment -> device planes [E,A,plane_stride] (rows >= R zero)."""
+        if out is None:
+            out = torch.zeros((self.E, self.A, self.plane_stride), dtype=torch.int8, device=self.device)
+        m = np.zeros((self.A, self.Rp, self.T1), np.int8)
+        hm = np.asarray(host_maps)
+        m[:, : hm.shape[1], :] = hm
+        out[e, :, : self.Rp * self.T1] = torch.as_tensor(m.reshape(self.A, -1), device=self.device)
+        return out
+
+    def plane_numpy(self, plane, R=None):
+        """One device plane [plane_stride] -> [R,T1] int8."""
+        R = self.Rp if R is None else R
+        return plane[: self.Rp * self.T1].reshape(self.Rp, self.T1)[:R].cpu().numpy()
+
     def maps_numpy(self, e=0, maps=None):
         """[A,R_e,T1] int8 view of one environment, as the reference's get_many returns it."""
         maps = self.maps if maps is None else maps

@@ -233,47 +233,8 @@ __global__ void shortest_paths_kernel(const uint16_t* __restrict__ grid_all, con
   const uint16_t* dist = dist_all + ((size_t)e * A + tslot[g]) * capCells * 4;
   int32_t* pc = path_cell + (size_t)g * Lcap;
   uint32_t* pm = path_meta + (size_t)g * Lcap;
-  int cell = start_cell[g], h = start_dir[g] & 3;
-  const int tcell = target_cell[g];
-  unsigned best_d = 0xFFFFFFFFu;  // carried across steps, as in the sequential definition
-  int n = 0, depth = 0;
-  while (cell != tcell && depth < max_depth) {
-    int r = cell / W, c = cell - r * W;
-    int act[3], nd[3];
-    int k = valid_moves(grid[cell], h, act, nd);
-    int best = -1;
-    for (int i = 0; i < k; i++) {
-      int nr = r + dr(nd[i]), nc = c + dc(nd[i]);
-      if (nr < 0 || nr >= H || nc < 0 || nc >= W) continue;
-      int idx = cell_idx[nr * W + nc];
-      if (idx < 0) continue;
-      unsigned dd = dist[idx * 4 + nd[i]];
-      if (dd != FLM_DIST_INF && dd < best_d) {
-        best = i;
-        best_d = dd;
-      }
-    }
-    if (best < 0) {
-      path_len[g] = -1;
-      return;
-    }
-    if (n < Lcap) {
-      pc[n] = cell;
-      pm[n] = (unsigned)h | ((unsigned)act[best] << 8) | ((unsigned)nd[best] << 16);
-    }
-    n++;
-    depth++;
-    cell = (r + dr(nd[best])) * W + c + dc(nd[best]);
-    h = nd[best];
-  }
-  if (depth < max_depth) {
-    if (n < Lcap) {
-      pc[n] = cell;
-      pm[n] = (unsigned)h | (4u << 8) | ((unsigned)h << 16);
-    }
-    n++;
-  }
-  path_len[g] = n;
+  path_len[g] = greedy_path(grid, cell_idx, dist, H, W, start_cell[g], start_dir[g] & 3, target_cell[g], max_depth, pc,
+                            pm, Lcap);
 }
 
 }  // namespace flm

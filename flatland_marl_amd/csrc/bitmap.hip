@@ -9,11 +9,11 @@ namespace flm {
 // entered its current rail (that decides the sign) and back-fills the steps spent on switch cells
 // with the rail that follows.  After a barrier every step writes its single byte.
 __global__ __launch_bounds__(256) void bitmaps_kernel(
-    const int32_t* __restrict__ path_cell, const int32_t* __restrict__ path_len, const int32_t* __restrict__ agent_of,
+    const int32_t* __restrict__ path_cell, const int32_t* __restrict__ path_len, const int32_t* __restrict__ agent_flat,
     const int32_t* __restrict__ pos_cell, const int32_t* __restrict__ target_cell, const int32_t* __restrict__ tpc_all,
     const int32_t* __restrict__ node_id_all, const int32_t* __restrict__ cell_rail_all,
-    const int32_t* __restrict__ edge_info_all, int A, int n_paths, int H, int W, int capR, int Rp, int T1,
-    int plane_stride, int Lcap, int shift, int8_t* __restrict__ planes, int32_t* __restrict__ err_out) {
+    const int32_t* __restrict__ edge_info_all, int A, int H, int W, int capR, int Rp, int T1, int plane_stride,
+    int Lcap, int shift, int8_t* __restrict__ planes, int32_t* __restrict__ err_out) {
   extern __shared__ __attribute__((aligned(16))) int lds[];
   int* s_cell = lds;             // [T1] predicted cell
   int* s_rail = lds + T1;        // [T1] rail in that cell or -1
@@ -22,11 +22,10 @@ __global__ __launch_bounds__(256) void bitmaps_kernel(
   int* s_oval = lds + 4 * T1;    // [T1] its sign
   int* s_misc = lds + 5 * T1;    // [0] kstop, [1] n (steps kept), [2] error
   const int gp = blockIdx.x;
-  const int e = gp / n_paths, j = gp - e * n_paths;
-  const int a = agent_of ? agent_of[gp] : j;
+  const int ga = agent_flat ? agent_flat[gp] : gp;  // e*A + a
+  const int e = ga / A;
   const int HW = H * W;
   const int tid = threadIdx.x;
-  const int ga = e * A + a;
   const int pos = pos_cell[ga], tgt = target_cell[ga];
   int tpc = tpc_all[ga];
   if (tpc < 1) tpc = 1;
@@ -231,9 +230,37 @@ __global__ __launch_bounds__(1024) void observations_kernel(const int8_t* __rest
   }
 }
 
+// Observation of selected agents only: request g asks for agent req_agent[g] (= e*A + a); the plane shown
+// as its own is own_planes[g] when given, else its plane in maps.  One workgroup per (1 KiB tile, request).
+__global__ __launch_bounds__(64) void observations_req_kernel(const int8_t* __restrict__ maps,
+                                                              const int32_t* __restrict__ req_agent,
+                                                              const int8_t* __restrict__ own_planes, int A,
+                                                              int plane_stride, uint8_t* __restrict__ out) {
+  const int g = blockIdx.y;
+  const int ga = req_agent[g];
+  const int e = ga / A, a = ga - e * A;
+  const size_t off = (size_t)blockIdx.x * 1024 + (size_t)threadIdx.x * 16;
+  if (off >= (size_t)plane_stride) return;
+  uint4 psum = make_uint4(0, 0, 0, 0), nsum = make_uint4(0, 0, 0, 0), mine = make_uint4(0, 0, 0, 0);
+  const int8_t* env = maps + (size_t)e * A * plane_stride + off;
+  for (int o = 0; o < A; o++) {
+    uint4 v = *reinterpret_cast<const uint4*>(env + (size_t)o * plane_stride);
+    if (o == a) mine = v;
+    else {
+      psum = add4(psum, pos_bits4(v));
+      nsum = add4(nsum, neg_bits4(v));
+    }
+  }
+  if (own_planes) mine = *reinterpret_cast<const uint4*>(own_planes + (size_t)g * plane_stride + off);
+  uint8_t* o = out + (size_t)g * 3 * plane_stride + off;
+  *reinterpret_cast<uint4*>(o) = mine;
+  *reinterpret_cast<uint4*>(o + plane_stride) = psum;
+  *reinterpret_cast<uint4*>(o + 2 * (size_t)plane_stride) = nsum;
+}
+
 }  // namespace flm
 
-extern "C" int flm_bitmaps(const int32_t* path_cell, const int32_t* path_len, const int32_t* agent_of,
+extern "C" int flm_bitmaps(const int32_t* path_cell, const int32_t* path_len, const int32_t* agent_flat,
                            const int32_t* pos_cell, const int32_t* target_cell, const int32_t* tpc,
                            const int32_t* node_id, const int32_t* cell_rail, const int32_t* edge_info, int E, int A,
                            int n_paths, int H, int W, int capR, int Rp, int T1, int plane_stride, int Lcap, int shift,
@@ -244,10 +271,10 @@ extern "C" int flm_bitmaps(const int32_t* path_cell, const int32_t* path_len, co
   if (E <= 0 || A <= 0 || n_paths <= 0 || H <= 0 || W <= 0 || capR <= 0 || Rp <= 0 || T1 <= 1 || Lcap <= 0 ||
       shift < 0 || plane_stride % 16 != 0 || (long long)plane_stride < (long long)Rp * T1 || T1 > 8000)
     return FLM_E_ARG;
-  if (!agent_of && n_paths != A) return FLM_E_ARG;
+  if (!agent_flat && n_paths != E * A) return FLM_E_ARG;
   size_t lds = sizeof(int) * (5 * (size_t)T1 + 4);
-  hipLaunchKernelGGL(flm::bitmaps_kernel, dim3(E * n_paths), dim3(256), lds, (hipStream_t)stream, path_cell, path_len,
-                     agent_of, pos_cell, target_cell, tpc, node_id, cell_rail, edge_info, A, n_paths, H, W, capR, Rp, T1,
+  hipLaunchKernelGGL(flm::bitmaps_kernel, dim3(n_paths), dim3(256), lds, (hipStream_t)stream, path_cell, path_len,
+                     agent_flat, pos_cell, target_cell, tpc, node_id, cell_rail, edge_info, A, H, W, capR, Rp, T1,
                      plane_stride, Lcap, shift, planes, err);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
@@ -307,6 +334,18 @@ extern "C" int flm_observations(const int8_t* maps, const int8_t* own, int E, in
                             : launch_obs_apw<2, false>(maps, own, E, A, plane_stride, obs, nw, stream);
   return nt ? launch_obs_apw<4, true>(maps, own, E, A, plane_stride, obs, nw, stream)
             : launch_obs_apw<4, false>(maps, own, E, A, plane_stride, obs, nw, stream);
+}
+
+extern "C" int flm_observations_req(const int8_t* maps, const int32_t* req_agent, const int8_t* own_planes, int n_req,
+                                    int E, int A, int plane_stride, uint8_t* out, void* stream) {
+  if (!maps || !req_agent || !out) return FLM_E_ARG;
+  if (n_req <= 0 || n_req > 65535 || E <= 0 || A <= 0 || A > 255 || plane_stride <= 0 || plane_stride % 16 != 0)
+    return FLM_E_ARG;
+  dim3 grid((plane_stride + 1023) / 1024, n_req);
+  hipLaunchKernelGGL(flm::observations_req_kernel, grid, dim3(64), 0, (hipStream_t)stream, maps, req_agent, own_planes,
+                     A, plane_stride, out);
+  FLM_CHECK_LAUNCH();
+  return FLM_OK;
 }
 
 extern "C" int flm_abi_version(void) { return 1; }

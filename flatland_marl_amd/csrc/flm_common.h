@@ -93,4 +93,49 @@ __device__ __forceinline__ int block_int_scan256(int v, int* scratch, int* total
   return base + inc - v;
 }
 
+// Greedy descent on a distance row (dist[cell_idx*4+heading], 0xFFFF = unreachable) from (cell, h)
+// to tcell: at most max_depth moves, ties broken left, forward, right; the best distance seen so far is
+// carried from step to step.  Elements are written while they fit in cap.  Returns the element count
+// (may exceed cap), or -1 when some step has no admissible move.
+__device__ __forceinline__ int greedy_path(const uint16_t* __restrict__ grid, const int32_t* __restrict__ cell_idx,
+                                           const uint16_t* __restrict__ dist, int H, int W, int cell, int h, int tcell,
+                                           int max_depth, int32_t* pc, uint32_t* pm, int cap) {
+  unsigned best_d = 0xFFFFFFFFu;
+  int n = 0, depth = 0;
+  while (cell != tcell && depth < max_depth) {
+    int r = cell / W, c = cell - r * W;
+    int act[3], nd[3];
+    int k = valid_moves(grid[cell], h, act, nd);
+    int best = -1;
+    for (int i = 0; i < k; i++) {
+      int nr = r + dr(nd[i]), nc = c + dc(nd[i]);
+      if (nr < 0 || nr >= H || nc < 0 || nc >= W) continue;
+      int idx = cell_idx[nr * W + nc];
+      if (idx < 0) continue;
+      unsigned dd = dist[idx * 4 + nd[i]];
+      if (dd != FLM_DIST_INF && dd < best_d) {
+        best = i;
+        best_d = dd;
+      }
+    }
+    if (best < 0) return -1;
+    if (n < cap) {
+      pc[n] = cell;
+      pm[n] = (unsigned)h | ((unsigned)act[best] << 8) | ((unsigned)nd[best] << 16);
+    }
+    n++;
+    depth++;
+    cell = (r + dr(nd[best])) * W + c + dc(nd[best]);
+    h = nd[best];
+  }
+  if (depth < max_depth) {  // closing element: stop on the cell reached
+    if (n < cap) {
+      pc[n] = cell;
+      pm[n] = (unsigned)h | (4u << 8) | ((unsigned)h << 16);
+    }
+    n++;
+  }
+  return n;
+}
+
 }  // namespace flm

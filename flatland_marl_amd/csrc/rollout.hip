@@ -1,0 +1,343 @@
+// Rollout-time kernels: alternative paths at a switch, and the occupancy-plane bookkeeping
+// (shift, delay behind the last train on the next rail, crash checks).
+#include "flm_common.h"
+
+namespace flm {
+
+// ---- alternative paths ------------------------------------------------------------------------------
+// One thread per request.  The branching prefix (the cell the agent stands on, then every switch cell
+// crossed before the first plain cell) is enumerated depth-first in the order left, forward, right;
+// every leaf is completed by a greedy descent of at most max_depth moves.
+#define FLM_ALT_STACK 32
+
+__global__ void altpaths_kernel(const uint16_t* __restrict__ grid_all, const int32_t* __restrict__ cell_idx_all,
+                                const uint16_t* __restrict__ dist_all, const int32_t* __restrict__ tslot,
+                                const int32_t* __restrict__ node_id_all, const int32_t* __restrict__ req_agent, int n_req,
+                                const int32_t* __restrict__ pos_cell, const int32_t* __restrict__ direction,
+                                const int32_t* __restrict__ target_cell, int A, int H, int W, int capCells,
+                                int max_depth, int cap_alt, int Lcap, int32_t* __restrict__ alt_count,
+                                int32_t* __restrict__ alt_len, int32_t* __restrict__ alt_cell,
+                                uint32_t* __restrict__ alt_meta, int32_t* __restrict__ err_out) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_req) return;
+  const int ga = req_agent[g];
+  const int e = ga / A;
+  const int HW = H * W;
+  const uint16_t* grid = grid_all + (size_t)e * HW;
+  const int32_t* cell_idx = cell_idx_all + (size_t)e * HW;
+  const int32_t* node_id = node_id_all + (size_t)e * HW;
+  const uint16_t* dist = dist_all + ((size_t)e * A + tslot[ga]) * capCells * 4;
+  const int tcell = target_cell[ga];
+  const int pos = pos_cell[ga], h0 = direction[ga] & 3;
+  int32_t* out_len = alt_len + (size_t)g * cap_alt;
+  int n_alt = 0, err = 0;
+
+  // prefix elements (cell, meta) and DFS frames over switch cells
+  int pre_cell[FLM_ALT_STACK + 2];
+  unsigned pre_meta[FLM_ALT_STACK + 2];
+  int f_cell[FLM_ALT_STACK], f_h[FLM_ALT_STACK], f_i[FLM_ALT_STACK], f_k[FLM_ALT_STACK];
+  int f_act[FLM_ALT_STACK][3], f_nd[FLM_ALT_STACK][3];
+
+  if (pos == tcell || pos < 0 || pos >= HW) {
+    err = FLM_AGENT_ASSERT_ERROR;
+  } else {
+    int act0[3], nd0[3];
+    const int k0 = valid_moves(grid[pos], h0, act0, nd0);
+    const int pr = pos / W, pc = pos - pr * W;
+    for (int i0 = 0; i0 < k0 && !err; i0++) {
+      // the first element is always recorded as "forward"
+      pre_cell[0] = pos;
+      pre_meta[0] = (unsigned)h0 | (2u << 8) | ((unsigned)nd0[i0] << 16);
+      int np = 1, depth = 0;
+      {
+        int nr = pr + dr(nd0[i0]), nc = pc + dc(nd0[i0]);
+        if (nr < 0 || nr >= H || nc < 0 || nc >= W) { err = FLM_AGENT_ASSERT_ERROR; break; }
+        f_cell[0] = nr * W + nc;
+        f_h[0] = nd0[i0];
+        f_i[0] = 0;
+        f_k[0] = valid_moves(grid[f_cell[0]], f_h[0], f_act[0], f_nd[0]);
+        depth = 1;
+      }
+      while (depth > 0 && !err) {
+        const int d = depth - 1;
+        const int cell = f_cell[d], h = f_h[d];
+        const int r = cell / W, c = cell - r * W;
+        if (node_id[cell] >= 0) {
+          if (f_i[d] > 0) np--;  // back from the previous branch
+          if (f_i[d] < f_k[d]) {
+            const int i = f_i[d]++;
+            pre_cell[np] = cell;
+            pre_meta[np] = (unsigned)h | ((unsigned)f_act[d][i] << 8) | ((unsigned)f_nd[d][i] << 16);
+            np++;
+            int nr = r + dr(f_nd[d][i]), nc = c + dc(f_nd[d][i]);
+            if (depth >= FLM_ALT_STACK || nr < 0 || nr >= H || nc < 0 || nc >= W) { err = FLM_AGENT_OVERFLOW; break; }
+            f_cell[depth] = nr * W + nc;
+            f_h[depth] = f_nd[d][i];
+            f_i[depth] = 0;
+            f_k[depth] = valid_moves(grid[f_cell[depth]], f_h[depth], f_act[depth], f_nd[depth]);
+            depth++;
+          } else {
+            depth--;
+          }
+        } else {
+          if (f_k[d] != 1) { err = FLM_AGENT_ASSERT_ERROR; break; }
+          if (n_alt >= cap_alt || np + 1 > Lcap) { err = FLM_AGENT_OVERFLOW; break; }
+          int32_t* oc = alt_cell + ((size_t)g * cap_alt + n_alt) * Lcap;
+          uint32_t* om = alt_meta + ((size_t)g * cap_alt + n_alt) * Lcap;
+          for (int q = 0; q < np; q++) { oc[q] = pre_cell[q]; om[q] = pre_meta[q]; }
+          oc[np] = cell;
+          om[np] = (unsigned)h | ((unsigned)f_act[d][0] << 8) | ((unsigned)f_nd[d][0] << 16);
+          const int base = np + 1;
+          if (cell == tcell) {
+            out_len[n_alt++] = base;
+          } else {
+            int nr = r + dr(f_nd[d][0]), nc = c + dc(f_nd[d][0]);
+            int n = -1;
+            if (nr >= 0 && nr < H && nc >= 0 && nc < W)
+              n = greedy_path(grid, cell_idx, dist, H, W, nr * W + nc, f_nd[d][0], tcell, max_depth, oc + base, om + base,
+                              Lcap - base);
+            if (n >= 0) {
+              if (base + n > Lcap) { err = FLM_AGENT_OVERFLOW; break; }
+              out_len[n_alt++] = base + n;
+            }
+          }
+          depth--;
+        }
+      }
+    }
+  }
+  alt_count[g] = err ? 0 : n_alt;
+  err_out[g] = err;
+}
+
+// ---- occupancy-plane bookkeeping ---------------------------------------------------------------------
+// One 256-thread workgroup per environment; the planes of an environment are [A][plane_stride] int8
+// with rows of T1 bytes.  All helpers are called by the whole workgroup.
+
+struct EnvMaps {
+  int8_t* base;
+  int A, Rp, T1, plane_stride;
+  __device__ __forceinline__ int8_t* plane(int a) const { return base + (size_t)a * plane_stride; }
+};
+
+// First rail with a non-zero entry in column ts of agent a's plane (0 when the column is empty) and the
+// entry found there.  s_tmp: one LDS int.
+__device__ int blk_rail_dir(const EnvMaps& m, int a, int ts, int* s_tmp, int* dir) {
+  if (threadIdx.x == 0) *s_tmp = 0x7FFFFFFF;
+  __syncthreads();
+  const int8_t* p = m.plane(a);
+  for (int r = threadIdx.x; r < m.Rp; r += blockDim.x)
+    if (p[(size_t)r * m.T1 + ts] != 0) atomicMin(s_tmp, r);
+  __syncthreads();
+  int rail = *s_tmp;
+  if (rail == 0x7FFFFFFF) rail = 0;
+  *dir = p[(size_t)rail * m.T1 + ts];
+  __syncthreads();
+  return rail;
+}
+
+// index of the first zero at or after `from` in a row, relative to `from`; 0 when there is none
+__device__ __forceinline__ int first_zero(const int8_t* row, int from, int T1) {
+  for (int t = from; t < T1; t++)
+    if (row[t] == 0) return t - from;
+  return 0;
+}
+
+__device__ __forceinline__ int thread_rail_at0(const EnvMaps& m, int a) {
+  const int8_t* p = m.plane(a);
+  for (int r = 0; r < m.Rp; r++)
+    if (p[(size_t)r * m.T1] != 0) return r;
+  return 0;
+}
+
+// The train (other than a, already departed) that leaves `rail` last, and its expected exit time.
+// s_tmp: one LDS int.  Returns exit time (0 = nobody), *last = that train.
+__device__ int blk_last_train_on_rail(const EnvMaps& m, const int32_t* status, const int32_t* tpc, int a, int rail,
+                                      int* s_tmp, int* last) {
+  if (threadIdx.x == 0) *s_tmp = 0;
+  __syncthreads();
+  for (int o = threadIdx.x; o < m.A; o += blockDim.x) {
+    if (o == a || status[o] == 0) continue;
+    const int8_t* p = m.plane(o);
+    const int8_t* row = p + (size_t)rail * m.T1;
+    int t = tpc[o];
+    int ex = -1;
+    if (row[0] != 0) {
+      ex = first_zero(row, 0, m.T1);
+    } else if (t >= 1 && t - 1 < m.T1 && row[t - 1] != 0) {
+      int orail = thread_rail_at0(m, o);
+      ex = 0;
+      if (orail != rail) ex = first_zero(p + (size_t)orail * m.T1, 0, m.T1);
+      ex += first_zero(row, ex, m.T1);
+    }
+    // sequential rule: a later train replaces the current one only with a strictly larger exit time
+    if (ex > 0) atomicMax(s_tmp, (ex << 12) | (4095 - o));
+  }
+  __syncthreads();
+  int key = *s_tmp;
+  __syncthreads();
+  if (key == 0) {
+    *last = 0;
+    return 0;
+  }
+  *last = 4095 - (key & 4095);
+  return key >> 12;
+}
+
+__device__ bool blk_headon_crash(const EnvMaps& m, const int32_t* status, const int32_t* tpc, int a, int rail, int dir,
+                                 int* s_tmp) {
+  int last;
+  int le = blk_last_train_on_rail(m, status, tpc, a, rail, s_tmp, &last);
+  if (le > 0) return m.plane(last)[(size_t)rail * m.T1 + le - 1] != dir;
+  return false;
+}
+
+__global__ __launch_bounds__(256) void check_crash_kernel(const int8_t* __restrict__ maps, const int32_t* __restrict__ status_all,
+                                                          const int32_t* __restrict__ tpc_all,
+                                                          const int32_t* __restrict__ pos_all,
+                                                          const int32_t* __restrict__ init_all,
+                                                          const int32_t* __restrict__ agent_sel,
+                                                          const int32_t* __restrict__ before_switch,
+                                                          const int32_t* __restrict__ next_cell, int A, int Rp, int T1,
+                                                          int plane_stride, int32_t* __restrict__ crash_out) {
+  __shared__ int s_tmp[2];
+  const int e = blockIdx.x;
+  const int a = agent_sel[e];
+  if (a < 0 || a >= A) return;
+  EnvMaps m{const_cast<int8_t*>(maps) + (size_t)e * A * plane_stride, A, Rp, T1, plane_stride};
+  const int32_t* status = status_all + (size_t)e * A;
+  const int32_t* tpc = tpc_all + (size_t)e * A;
+  const int32_t* pos = pos_all + (size_t)e * A;
+  bool crash = false;
+  if (status[a] == 0) {
+    const int init = init_all[(size_t)e * A + a];
+    if (threadIdx.x == 0) s_tmp[1] = 0;
+    __syncthreads();
+    for (int o = threadIdx.x; o < A; o += blockDim.x)
+      if (o != a && pos[o] == init) s_tmp[1] = 1;
+    __syncthreads();
+    crash = s_tmp[1] != 0;
+    __syncthreads();
+    if (!crash) {
+      int dir;
+      int rail = blk_rail_dir(m, a, 1, s_tmp, &dir);
+      crash = blk_headon_crash(m, status, tpc, a, rail, dir, s_tmp);
+    }
+  } else if (before_switch[e]) {
+    int t = tpc[a];
+    if (t >= T1) t = T1 - 1;
+    int dir;
+    int rail = blk_rail_dir(m, a, t, s_tmp, &dir);
+    crash = blk_headon_crash(m, status, tpc, a, rail, dir, s_tmp);
+  } else {
+    const int nxt = next_cell[e];
+    if (threadIdx.x == 0) s_tmp[1] = 0;
+    __syncthreads();
+    if (nxt >= 0)
+      for (int o = threadIdx.x; o < A; o += blockDim.x)
+        if (o != a && pos[o] == nxt) s_tmp[1] = 1;
+    __syncthreads();
+    crash = s_tmp[1] != 0;
+  }
+  if (threadIdx.x == 0) crash_out[e] = crash ? 1 : 0;
+}
+
+// Shift agent a's plane by `delay` to the right, clear the first delay+tpc columns, keep the current rail
+// for tpc columns and hold the next rail for `delay` more columns.
+__device__ void blk_delay(const EnvMaps& m, const int32_t* tpc, int a, int rail, int dir, int delay, int* s_tmp) {
+  int odir;
+  const int orail = blk_rail_dir(m, a, 0, s_tmp, &odir);
+  const int t = tpc[a];
+  int8_t* p = m.plane(a);
+  int z = delay + t;
+  if (z > m.T1) z = m.T1;
+  for (int r = threadIdx.x; r < m.Rp; r += blockDim.x) {
+    int8_t* row = p + (size_t)r * m.T1;
+    for (int c = m.T1 - 1; c >= z; c--) row[c] = row[c - delay];
+    for (int c = 0; c < z; c++) row[c] = 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int c = 0; c < t && c < m.T1; c++) p[(size_t)orail * m.T1 + c] = (int8_t)odir;
+    for (int c = t; c < t + delay && c < m.T1; c++) p[(size_t)rail * m.T1 + c] = (int8_t)dir;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void update_bitmaps_kernel(int8_t* __restrict__ maps, const int32_t* __restrict__ status_all,
+                                                             const int32_t* __restrict__ tpc_all,
+                                                             const int32_t* __restrict__ agent_sel,
+                                                             const int32_t* __restrict__ before_switch, int A, int Rp,
+                                                             int T1, int plane_stride) {
+  __shared__ int s_tmp[2];
+  const int e = blockIdx.x;
+  const int a = agent_sel[e];
+  if (a < 0 || a >= A) return;
+  EnvMaps m{maps + (size_t)e * A * plane_stride, A, Rp, T1, plane_stride};
+  const int32_t* status = status_all + (size_t)e * A;
+  const int32_t* tpc = tpc_all + (size_t)e * A;
+  int8_t* p = m.plane(a);
+  if (before_switch[e]) {
+    int t = tpc[a];
+    if (t >= T1) t = T1 - 1;
+    int dir, last;
+    const int rail = blk_rail_dir(m, a, t, s_tmp, &dir);
+    const int le = blk_last_train_on_rail(m, status, tpc, a, rail, s_tmp, &last);
+    if (le > 0) {
+      const int cur = first_zero(p + (size_t)rail * T1, t, T1) + t;
+      if (cur <= le) blk_delay(m, tpc, a, rail, dir, le + t - cur, s_tmp);
+    }
+  }
+  // one step passes: every row moves one column to the left
+  for (int r = threadIdx.x; r < Rp; r += blockDim.x) {
+    int8_t* row = p + (size_t)r * T1;
+    for (int c = 0; c + 1 < T1; c++) row[c] = row[c + 1];
+    row[T1 - 1] = 0;
+  }
+}
+
+}  // namespace flm
+
+extern "C" int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const uint16_t* dist, const int32_t* tslot,
+                            const int32_t* node_id, const int32_t* req_agent, int n_req, const int32_t* pos_cell,
+                            const int32_t* direction, const int32_t* target_cell, int E, int A, int H, int W,
+                            int capCells, int max_depth, int cap_alt, int Lcap, int32_t* alt_count, int32_t* alt_len,
+                            int32_t* alt_cell, uint32_t* alt_meta, int32_t* err, void* stream) {
+  if (!grid || !cell_idx || !dist || !tslot || !node_id || !req_agent || !pos_cell || !direction || !target_cell ||
+      !alt_count || !alt_len || !alt_cell || !alt_meta || !err)
+    return FLM_E_ARG;
+  if (E <= 0 || A <= 0 || H <= 0 || W <= 0 || n_req <= 0 || capCells <= 0 || max_depth < 0 || cap_alt <= 0 ||
+      Lcap < max_depth + 4)
+    return FLM_E_ARG;
+  hipLaunchKernelGGL(flm::altpaths_kernel, dim3((n_req + 63) / 64), dim3(64), 0, (hipStream_t)stream, grid, cell_idx, dist,
+                     tslot, node_id, req_agent, n_req, pos_cell, direction, target_cell, A, H, W, capCells, max_depth,
+                     cap_alt, Lcap, alt_count, alt_len, alt_cell, alt_meta, err);
+  FLM_CHECK_LAUNCH();
+  return FLM_OK;
+}
+
+extern "C" int flm_check_crash(const int8_t* maps, const int32_t* status, const int32_t* tpc, const int32_t* pos_cell,
+                               const int32_t* init_cell, const int32_t* agent_sel, const int32_t* before_switch,
+                               const int32_t* next_cell, int E, int A, int Rp, int T1, int plane_stride, int32_t* crash,
+                               void* stream) {
+  if (!maps || !status || !tpc || !pos_cell || !init_cell || !agent_sel || !before_switch || !next_cell || !crash)
+    return FLM_E_ARG;
+  if (E <= 0 || A <= 0 || A > 4095 || Rp <= 0 || T1 <= 1 || T1 > 8000 || (long long)plane_stride < (long long)Rp * T1)
+    return FLM_E_ARG;
+  hipLaunchKernelGGL(flm::check_crash_kernel, dim3(E), dim3(256), 0, (hipStream_t)stream, maps, status, tpc, pos_cell,
+                     init_cell, agent_sel, before_switch, next_cell, A, Rp, T1, plane_stride, crash);
+  FLM_CHECK_LAUNCH();
+  return FLM_OK;
+}
+
+extern "C" int flm_update_bitmaps(int8_t* maps, const int32_t* status, const int32_t* tpc, const int32_t* agent_sel,
+                                  const int32_t* before_switch, int E, int A, int Rp, int T1, int plane_stride,
+                                  void* stream) {
+  if (!maps || !status || !tpc || !agent_sel || !before_switch) return FLM_E_ARG;
+  if (E <= 0 || A <= 0 || A > 4095 || Rp <= 0 || T1 <= 1 || T1 > 8000 || (long long)plane_stride < (long long)Rp * T1)
+    return FLM_E_ARG;
+  hipLaunchKernelGGL(flm::update_bitmaps_kernel, dim3(E), dim3(256), 0, (hipStream_t)stream, maps, status, tpc, agent_sel,
+                     before_switch, A, Rp, T1, plane_stride);
+  FLM_CHECK_LAUNCH();
+  return FLM_OK;
+}

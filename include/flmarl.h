@@ -102,11 +102,11 @@ int flm_shortest_paths(const uint16_t* grid, const int32_t* cell_idx, const uint
  * Replaces prediction_from_path + cells_seq_from_prediction, src/predictions.py:85-143,
  * _bitmap_from_cells_seq, src/rail_observations.py:323-407, and the shift of get_many
  * (src/rail_observations.py:92-93) / get_altmaps (:105-107).
- *   n_paths paths per environment: path_* are [E,n_paths,Lcap]; agent_of [E,n_paths] int32 gives the
- *   agent each path belongs to (NULL = identity, n_paths == A); pos_cell [E,A] the agent's virtual
- *   position; tpc [E,A] time steps per cell; planes [E,n_paths,plane_stride] int8 out;
- *   err [E,n_paths] int32 out. */
-int flm_bitmaps(const int32_t* path_cell, const int32_t* path_len, const int32_t* agent_of,
+ *   n_paths paths in all: path_cell [n_paths,Lcap], path_len [n_paths]; agent_flat [n_paths] int32 gives
+ *   the agent (e*A + a) each path belongs to (NULL = identity, n_paths == E*A); pos_cell [E,A] the agent's
+ *   virtual position (src/predictions.py:89-94); tpc [E,A] time steps per cell;
+ *   planes [n_paths,plane_stride] int8 out; err [n_paths] int32 out. */
+int flm_bitmaps(const int32_t* path_cell, const int32_t* path_len, const int32_t* agent_flat,
                 const int32_t* pos_cell, const int32_t* target_cell, const int32_t* tpc,
                 const int32_t* node_id, const int32_t* cell_rail, const int32_t* edge_info, int E, int A,
                 int n_paths, int H, int W, int capR, int Rp, int T1, int plane_stride, int Lcap, int shift,
@@ -121,6 +121,48 @@ int flm_bitmaps(const int32_t* path_cell, const int32_t* path_len, const int32_t
  * A <= 255. */
 int flm_observations(const int8_t* maps, const int8_t* own, int E, int A, int plane_stride, uint8_t* obs,
                      void* stream);
+
+/* The same observation for selected agents only (rollout: the agents that consult the network this step).
+ * Replaces one ObsPreprocessor.get_obs call per request, src/preprocessing.py:61-74.
+ *   req_agent [n_req] int32 = e*A + a; own_planes [n_req,plane_stride] int8 or NULL (an alternative plane
+ *   shown instead of the agent's own; the agent's plane in maps is what is left out of the heat sums,
+ *   src/preprocessing.py:25-26); out [n_req,3,plane_stride] uint8.  n_req <= 65535, A <= 255. */
+int flm_observations_req(const int8_t* maps, const int32_t* req_agent, const int8_t* own_planes, int n_req, int E,
+                         int A, int plane_stride, uint8_t* out, void* stream);
+
+/* Alternative paths of agents that stand in front of a switch.
+ * Replaces get_altpaths, src/utils/shortest_path.py:92-163 (called through
+ * ShortestPathPredictorForRailEnv.get_altpaths, src/predictions.py:74-83, with max_depth = 500).
+ *   req_agent [n_req] int32: e*A + a of each request; pos_cell/direction/target_cell [E,A] as above
+ *   alt_count [n_req] out; alt_len [n_req,cap_alt] out; alt_cell/alt_meta [n_req,cap_alt,Lcap] out in the
+ *   path encoding of flm_shortest_paths; err [n_req] out (FLM_AGENT_ASSERT_ERROR where the reference's
+ *   assertions at :108/:125 fail, FLM_AGENT_OVERFLOW when cap_alt, Lcap or 32 consecutive switch cells
+ *   are exceeded).  Lcap >= max_depth + 4.
+ * Alternatives come in the reference's order: moves left, forward, right, depth first. */
+int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const uint16_t* dist, const int32_t* tslot,
+                 const int32_t* node_id, const int32_t* req_agent, int n_req, const int32_t* pos_cell,
+                 const int32_t* direction, const int32_t* target_cell, int E, int A, int H, int W, int capCells,
+                 int max_depth, int cap_alt, int Lcap, int32_t* alt_count, int32_t* alt_len, int32_t* alt_cell,
+                 uint32_t* alt_meta, int32_t* err, void* stream);
+
+/* Would the selected agent of each environment crash if it moved now?
+ * Replaces RailObsForRailEnv.check_crash with _is_cell_occupied, _check_headon_crash, _last_train_on_rail
+ * and _get_rail_dir, src/rail_observations.py:161-164, 182-230, 257-299.
+ *   maps [E,A,plane_stride] int8; status/tpc/pos_cell/init_cell [E,A] int32 (pos_cell -1 = not on the grid)
+ *   agent_sel [E] int32 (-1 = skip the environment), before_switch [E] int32, next_cell [E] int32 (the
+ *   next cell of the agent's path, -1 when the path is empty; used when the agent is neither
+ *   READY_TO_DEPART nor before a switch); crash [E] int32 out (untouched where agent_sel < 0). */
+int flm_check_crash(const int8_t* maps, const int32_t* status, const int32_t* tpc, const int32_t* pos_cell,
+                    const int32_t* init_cell, const int32_t* agent_sel, const int32_t* before_switch,
+                    const int32_t* next_cell, int E, int A, int Rp, int T1, int plane_stride, int32_t* crash,
+                    void* stream);
+
+/* One time step passes for the selected agent of each environment: its plane moves one column to the
+ * left; before a switch the agent is first delayed behind the last train on the rail it is about to enter.
+ * Replaces RailObsForRailEnv.update_bitmaps and _delay, src/rail_observations.py:167-180, 232-252.
+ * maps is updated in place. */
+int flm_update_bitmaps(int8_t* maps, const int32_t* status, const int32_t* tpc, const int32_t* agent_sel,
+                       const int32_t* before_switch, int E, int A, int Rp, int T1, int plane_stride, void* stream);
 
 #ifdef __cplusplus
 }

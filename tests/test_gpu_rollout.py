@@ -1,0 +1,96 @@
+"""The package's drop-in builder classes replay the golden rollout traces (needs an MI355X).
+
+The traces were recorded by driving the reference's RailObsForRailEnv / ObsPreprocessor with
+oracle/trace_driver.py; here the same driver runs the drop-in classes, whose work goes through the C ABI.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from tests.golden_util import GOLDEN, load_env, load_golden, dense_from_runs, path_rows_of
+from tests.test_oracle_rollout import shim_env, compare_trace
+
+pytestmark = pytest.mark.gpu
+TRACES = sorted(glob.glob(os.path.join(GOLDEN, "rollout", "*.npz")))
+
+
+@pytest.mark.parametrize("path", TRACES, ids=[os.path.basename(p)[:-4] for p in TRACES])
+def test_dropin_replays_trace(path):
+    from flatland_marl_amd.rail_observations import RailObsForRailEnv
+    from flatland_marl_amd.predictions import ShortestPathPredictorForRailEnv
+    from flatland_marl_amd.preprocessing import ObsPreprocessor
+    from oracle.trace_driver import run_trace
+    gold = dict(np.load(path))
+    name = os.path.basename(path).split("_a")[0]
+    A, depth, steps = int(gold["agents"]), int(gold["depth"]), int(gold["steps"])
+    ob = RailObsForRailEnv(ShortestPathPredictorForRailEnv(depth))
+    env = shim_env(load_env(name), ob, A)
+    rec, snaps = run_trace(env, ob, ObsPreprocessor(int(gold["max_rails"]), False), steps)
+    compare_trace(rec, snaps, gold)
+
+
+@pytest.mark.parametrize("name", ["Test_0_Level_0", "Test_2_Level_0", "Test_4_Level_1", "Test_7_Level_0"])
+def test_dropin_graph_and_get_many(name):
+    """Attributes and get_many of the drop-in builder against the reference's goldens."""
+    from flatland_marl_amd.rail_observations import RailObsForRailEnv
+    from flatland_marl_amd.predictions import ShortestPathPredictorForRailEnv
+    gold = load_golden(name, 150)
+    ob = RailObsForRailEnv(ShortestPathPredictorForRailEnv(150))
+    env = shim_env(load_env(name), ob, None)
+    maps, info = env.reset()
+    assert ob.num_rails == gold["info"].shape[0]
+    assert [ob.id_node_to_cell[i] for i in range(len(ob.id_node_to_cell))] == [tuple(x) for x in gold["node_cells"]]
+    for e in range(ob.num_rails):
+        src, dst, ln = ob.info[e]
+        assert (src.id_node, src.cardinal_point, dst.id_node, dst.cardinal_point, ln) == tuple(gold["info"][e])
+        want = gold["edge_cells"][gold["edge_cell_off"][e]:gold["edge_cell_off"][e + 1]]
+        assert [(c[0][0], c[0][1], c[1]) for c in ob.id_edge_to_cells[e]] == [tuple(x) for x in want]
+    assert maps.dtype == np.int64 and maps.shape == tuple(gold["maps_shape"])
+    assert np.array_equal(maps, dense_from_runs(gold["maps_runs"], maps.shape))
+    assert env.obs_builder.get_many() is None
+    for a in range(len(env.agents)):
+        rows = path_rows_of(gold, a)
+        p = ob.paths[a]
+        got = [(e.position[0], e.position[1], e.direction, int(e.next_action_element.action),
+                e.next_action_element.next_position[0], e.next_action_element.next_position[1],
+                e.next_action_element.next_direction) for e in p]
+        assert got == [tuple(r) for r in rows]
+
+
+@pytest.mark.parametrize("name", ["Test_1_Level_0", "Test_3_Level_1", "Test_8_Level_0"])
+def test_altmaps_against_reference(name):
+    """get_altmaps of the drop-in builder at each agent's first cell before a switch."""
+    from flatland_marl_amd.rail_observations import RailObsForRailEnv
+    from flatland_marl_amd.predictions import ShortestPathPredictorForRailEnv
+    depth = 150
+    gold = load_golden(name, depth)
+    ob = RailObsForRailEnv(ShortestPathPredictorForRailEnv(depth))
+    env = shim_env(load_env(name), ob, None)
+    env.reset()
+    n_alt_total = int(np.maximum(gold["alt_count"], 0).sum())
+    want_maps = dense_from_runs(gold["alt_maps_runs"], (n_alt_total, ob.num_rails, depth + 1))
+    flat = 0
+    for a, k, cnt in zip(gold["alt_agent"], gold["alt_k"], gold["alt_count"]):
+        el = path_rows_of(gold, a)[k]
+        ag = env.agents[a]
+        ag.status, ag.position, keep = 1, (int(el[0]), int(el[1])), ag.direction
+        ag.direction = int(el[2])
+        try:
+            if cnt < 0:
+                with pytest.raises((AssertionError, KeyError, IndexError)):
+                    ob.get_altmaps(a)
+                continue
+            bms, paths = ob.get_altmaps(a)
+        finally:
+            ag.status, ag.position, ag.direction = 0, None, keep
+        assert len(bms) == cnt
+        for i in range(cnt):
+            w = gold["alt_path_rows"][gold["alt_path_off"][flat]:gold["alt_path_off"][flat + 1]]
+            got = [(e.position[0], e.position[1], e.direction, int(e.next_action_element.action),
+                    e.next_action_element.next_position[0], e.next_action_element.next_position[1],
+                    e.next_action_element.next_direction) for e in paths[i]]
+            assert got == [tuple(r) for r in w]
+            assert np.array_equal(bms[i], want_maps[flat])
+            flat += 1

@@ -19,6 +19,7 @@ def shim_env(fx, builder, A):
     return RailEnv.from_fixture(fx, builder, num_agents=A)
 
 
+
 def compare_trace(rec, snaps, gold):
     n = int(gold["n_steps_run"])
     assert int(rec["n_steps_run"]) == n
