@@ -256,17 +256,19 @@ class ObservationBatch:
         dev = self.device
         crash = torch.zeros((self.E,), dtype=torch.int32, device=dev)
         init = self.start_cell if init_cell is None else init_cell
-        call("flm_check_crash", ptr(maps), ptr(self.status), ptr(self.tpc), ptr(self.pos_cell), ptr(init),
-             ptr(_dev_i32(agent_sel, dev)), ptr(_dev_i32(before_switch, dev)), ptr(_dev_i32(next_cell, dev)), self.E,
-             self.A, self.Rp, self.T1, self.plane_stride, ptr(crash), self.stream.cuda_stream)
+        # the three selector tensors must stay referenced until the launch has been enqueued
+        sel, bsw, nxt = _dev_i32(agent_sel, dev), _dev_i32(before_switch, dev), _dev_i32(next_cell, dev)
+        call("flm_check_crash", ptr(maps), ptr(self.status), ptr(self.tpc), ptr(self.pos_cell), ptr(init), ptr(sel),
+             ptr(bsw), ptr(nxt), self.E, self.A, self.Rp, self.T1, self.plane_stride, ptr(crash),
+             self.stream.cuda_stream)
         return crash
 
     def update_bitmaps(self, maps, agent_sel, before_switch):
         """update_bitmaps (src/rail_observations.py:232-252) for one selected agent per environment, in place."""
         dev = self.device
-        call("flm_update_bitmaps", ptr(maps), ptr(self.status), ptr(self.tpc), ptr(_dev_i32(agent_sel, dev)),
-             ptr(_dev_i32(before_switch, dev)), self.E, self.A, self.Rp, self.T1, self.plane_stride,
-             self.stream.cuda_stream)
+        sel, bsw = _dev_i32(agent_sel, dev), _dev_i32(before_switch, dev)
+        call("flm_update_bitmaps", ptr(maps), ptr(self.status), ptr(self.tpc), ptr(sel), ptr(bsw), self.E, self.A,
+             self.Rp, self.T1, self.plane_stride, self.stream.cuda_stream)
         return maps
 
     # ------------------------------------------------------------------ host views (tests, drop-in classes)
