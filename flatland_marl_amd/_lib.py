@@ -30,9 +30,18 @@ _SIGNATURES = {
     "flm_altpaths": [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     "flm_check_crash": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     "flm_update_bitmaps": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "flm_dqn_param_count": [_i, _i],
+    "flm_dqn_forward_workspace": [_i, _i],
+    "flm_dqn_learn_workspace": [_i, _i, _i],
+    "flm_dqn_forward": [_p, _p, _i, _i, _i, _p, _p, _p],
+    "flm_obs_to_f32": [_p, _i, _i, _i, _i, _p, _p],
+    "flm_dqn_learn_grads": [_p, _p, _p, _p, _p, _p, _p, C.c_float, _i, _i, _i, _p, _p, _p, _p],
+    "flm_dqn_adam": [_p, _p, _p, _p, C.c_long, C.c_double, C.c_double, C.c_double, C.c_double, _i, _p],
+    "flm_dqn_soft_update": [_p, _p, C.c_long, C.c_double, _p],
     "flm_dev_set_option": [_i, _i],
 }
 
+_LONG_RESULT = {"flm_dqn_param_count", "flm_dqn_forward_workspace", "flm_dqn_learn_workspace"}
 _lib = None
 
 
@@ -55,7 +64,7 @@ def load():
         for name, args in _SIGNATURES.items():
             fn = getattr(lib, name)
             fn.argtypes = args
-            fn.restype = C.c_int
+            fn.restype = C.c_long if name in _LONG_RESULT else C.c_int
         if lib.flm_abi_version() != ABI_VERSION:
             raise FlmError("libflmarl_hip.so ABI %d, expected %d" % (lib.flm_abi_version(), ABI_VERSION))
         _lib = lib
@@ -68,6 +77,11 @@ def ptr(t):
         return None
     assert t.is_contiguous()
     return t.data_ptr()
+
+
+def query(name, *args):
+    """Size queries (return a count, not a status)."""
+    return int(getattr(load(), name)(*args))
 
 
 def call(name, *args):

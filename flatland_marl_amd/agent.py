@@ -1,0 +1,160 @@
+"""Drop-in for the reference's DQNAgent and ReplayBuffer (src/agent.py:17-198).
+
+Same constructor arguments (args.prediction_depth, lr, buffer_size, batch_size, update_every, gamma,
+tau), methods and attributes.  Forward, loss, backward, Adam and the soft update are HIP kernels over flat
+fp32 parameter buffers; with more than one process the gradient is averaged over ranks (one all-reduce
+of the flat buffer) before the optimizer step.
+"""
+import copy
+import os
+import random
+from collections import namedtuple, deque
+from collections.abc import Iterable
+
+import numpy as np
+import torch
+
+from . import parallel
+from ._lib import call, ptr, query
+from .model import Dueling_DQN
+
+device = torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
+
+
+class FlatAdam:
+    """torch.optim.Adam (default betas/eps, no weight decay) over the network's flat parameter buffer."""
+
+    def __init__(self, network, lr, betas=(0.9, 0.999), eps=1e-8):
+        self.network = network
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.step_count = 0
+        self.m = self.v = self.grads = None
+
+    def _ensure(self):
+        flat = self.network.flat_params()
+        if self.m is None or self.m.device != flat.device:
+            self.m = torch.zeros_like(flat)
+            self.v = torch.zeros_like(flat)
+            self.grads = torch.zeros_like(flat)
+        return flat
+
+    def zero_grad(self):
+        self._ensure()
+        self.grads.zero_()
+
+    def step(self):
+        flat = self._ensure()
+        self.step_count += 1
+        call("flm_dqn_adam", ptr(flat), ptr(self.grads), ptr(self.m), ptr(self.v), flat.numel(), float(self.lr),
+             float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_count,
+             torch.cuda.current_stream(flat.device).cuda_stream)
+
+
+class DQNAgent:
+    """Interacts with and learns from the environment."""
+
+    def __init__(self, args, action_space, bitmap_height, double_dqn=True):
+        self.args = args
+        self.width = args.prediction_depth + 1
+        self.height = bitmap_height
+        self.action_space = action_space
+        self.double_dqn = double_dqn
+        if not double_dqn:
+            raise NotImplementedError("only the double-DQN target (the reference's default) is implemented")
+        self.qnetwork_local = Dueling_DQN(self.width, self.height, action_space).to(device)
+        self.qnetwork_target = copy.deepcopy(self.qnetwork_local)
+        self.optimizer = FlatAdam(self.qnetwork_local, lr=self.args.lr)
+        self.memory = ReplayBuffer(action_space, self.args.buffer_size, self.args.batch_size, self.width, self.height)
+        self.t_step = 0
+        self.last_loss = None
+        self._ws = None
+
+    def save(self, filename):
+        torch.save(self.qnetwork_local.state_dict(), filename + ".local")
+        torch.save(self.qnetwork_target.state_dict(), filename + ".target")
+
+    def load(self, filename):
+        if os.path.exists(filename + ".local"):
+            self.qnetwork_local.load_state_dict(torch.load(filename + ".local"))
+        if os.path.exists(filename + ".target"):
+            self.qnetwork_target.load_state_dict(torch.load(filename + ".target"))
+
+    def step(self, state, action, reward, next_state, done, train=True):
+        self.memory.add(state, action, reward, next_state, done)
+        self.t_step = (self.t_step + 1) % self.args.update_every
+        if self.t_step == 0:
+            if len(self.memory) > self.args.batch_size:
+                experiences = self.memory.sample()
+                if train:
+                    self.learn(experiences, self.args.gamma)
+
+    def act(self, state, eps=0.):
+        """Q-values [action_space] (device tensor) of one observation [3*max_rails, depth+1]."""
+        state = torch.from_numpy(np.ascontiguousarray(state)).float().unsqueeze(0).unsqueeze(0).to(device)
+        self.qnetwork_local.eval()
+        with torch.no_grad():
+            action_values = self.qnetwork_local(state)
+        self.qnetwork_local.train()
+        return action_values[0]
+
+    def learn(self, experiences, gamma):
+        states, actions, rewards, next_states, dones = experiences
+        B = states.size(0)
+        local = self.qnetwork_local.flat_params()
+        target = self.qnetwork_target.flat_params()
+        dev = local.device
+        n_ws = query("flm_dqn_learn_workspace", B, self.height, self.width)
+        if self._ws is None or self._ws.numel() < n_ws or self._ws.device != dev:
+            self._ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
+        s = states.to(dev, torch.float32).contiguous().view(B, self.height, self.width)
+        sn = next_states.to(dev, torch.float32).contiguous().view(B, self.height, self.width)
+        a = actions.to(dev, torch.int64).contiguous()
+        r = rewards.to(dev, torch.float32).contiguous()
+        d = dones.to(dev, torch.float32).contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        self.optimizer.zero_grad()
+        call("flm_dqn_learn_grads", ptr(local), ptr(target), ptr(s), ptr(sn), ptr(a), ptr(r), ptr(d), float(gamma), B,
+             self.height, self.width, ptr(self._ws), ptr(self.optimizer.grads), ptr(loss),
+             torch.cuda.current_stream(dev).cuda_stream)
+        parallel.allreduce_mean_(self.optimizer.grads)      # data parallel: one bucket, RCCL over xGMI
+        self.optimizer.step()
+        self.last_loss = loss
+        self.soft_update(self.qnetwork_local, self.qnetwork_target, self.args.tau)
+
+    def soft_update(self, local_model, target_model, tau):
+        local, target = local_model.flat_params(), target_model.flat_params()
+        call("flm_dqn_soft_update", ptr(target), ptr(local), local.numel(), float(tau),
+             torch.cuda.current_stream(local.device).cuda_stream)
+
+
+class ReplayBuffer:
+    """Fixed-size buffer of experience tuples (host memory, uniform sampling), as in the reference."""
+
+    def __init__(self, action_space, buffer_size, batch_size, width, height):
+        self.action_space = action_space
+        self.memory = deque(maxlen=buffer_size)
+        self.batch_size = batch_size
+        self.width = width
+        self.height = height
+        self.experience = namedtuple("Experience", field_names=["state", "action", "reward", "next_state", "done"])
+
+    def add(self, state, action, reward, next_state, done):
+        e = self.experience(np.expand_dims(state, 0), action, reward, np.expand_dims(next_state, 0), done)
+        self.memory.append(e)
+
+    def sample(self):
+        experiences = random.sample(self.memory, k=self.batch_size)
+        states = torch.from_numpy(self._stack([e.state for e in experiences if e is not None])).float().to(device)
+        actions = torch.from_numpy(self._stack([e.action for e in experiences if e is not None])).long().to(device)
+        rewards = torch.from_numpy(self._stack([e.reward for e in experiences if e is not None])).float().to(device)
+        next_states = torch.from_numpy(self._stack([e.next_state for e in experiences if e is not None])).float().to(device)
+        dones = torch.from_numpy(self._stack([e.done for e in experiences if e is not None]).astype(np.uint8)).float().to(device)
+        return states, actions, rewards, next_states, dones
+
+    def __len__(self):
+        return len(self.memory)
+
+    def _stack(self, items):
+        if isinstance(items[0], Iterable):
+            return np.reshape(np.array(items), (len(items), 1, self.height, self.width))
+        return np.reshape(np.array(items), (len(items)))

@@ -1,0 +1,571 @@
+// Dueling Double-DQN of flatland-marl on gfx950: fp32 throughout, matrix products on the fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: exact fp32 fused multiply-adds, no reduced-precision inputs).
+//
+// Network (src/model.py:11-43 of the reference), H3 = 3*max_rails rows, T1 = depth+1 columns:
+//   x[B,1,H3,T1] -> Conv2d(1,64,(1,T1)) + ReLU  == per row a dot product with 64 filters
+//                -> flatten as [c*H3 + h]       -> fc1_adv, fc1_val (64*H3 -> 512) + ReLU
+//                -> fc2_adv (512 -> 2), fc2_val (512 -> 1) -> q = val + adv - mean(adv)
+// Parameters live in one flat fp32 buffer in the order of the module's parameters():
+//   conv1.weight[64,T1] conv1.bias[64] fc1_adv.weight[512,K1] fc1_adv.bias[512] fc1_val.weight[512,K1]
+//   fc1_val.bias[512] fc2_adv.weight[2,512] fc2_adv.bias[2] fc2_val.weight[1,512] fc2_val.bias[1],  K1 = 64*H3.
+#include "flm_common.h"
+
+namespace flm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct DqnLayout {
+  int H3, T1;
+  long K1;
+  long conv_w, conv_b, a1_w, a1_b, v1_w, v1_b, a2_w, a2_b, v2_w, v2_b, total;
+  __host__ __device__ DqnLayout(int h3, int t1) : H3(h3), T1(t1) {
+    K1 = 64L * h3;
+    conv_w = 0;
+    conv_b = conv_w + 64L * t1;
+    a1_w = conv_b + 64;
+    a1_b = a1_w + 512 * K1;
+    v1_w = a1_b + 512;
+    v1_b = v1_w + 512 * K1;
+    a2_w = v1_b + 512;
+    a2_b = a2_w + 1024;
+    v2_w = a2_b + 2;
+    v2_b = v2_w + 512;
+    total = v2_b + 1;
+  }
+};
+
+// ---- tiled fp32 MFMA GEMM ---------------------------------------------------------------------------
+// C[M,N] (+)= A[M,K] * B[K,N].  A is addressed A[m*lda + k] when A_KC (k contiguous) else A[k*lda + m];
+// B is B[n*ldb + k] when B_KC else B[k*ldb + n].  Workgroup tile 128x128x16, 4 waves as 2x2, each wave
+// 2x2 MFMA tiles of 32x32.  blockIdx.z selects a batch / K-slice through the z strides.
+enum { EPI_PLAIN = 0, EPI_CONV = 1, EPI_MASK = 2 };
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;   // per n, or nullptr
+  const float* mask;   // EPI_MASK: same indexing as C; output kept where mask > 0
+  int M, N, K;
+  long lda, ldb, ldc;
+  long a_zs, b_zs, c_zs;
+  int relu, accumulate;
+  int H3;              // EPI_CONV: rows are (b,h) with h < H3; C index = b*N*H3 + n*H3 + h
+};
+
+#define GBM 128
+#define GBN 128
+#define GBK 16
+#define APAD 2   // k-contiguous sources are transposed on the way into LDS; this pad spreads the 4 k-groups over banks
+#define BPAD 4
+
+template <bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[GBK][GBM + BPAD + APAD];
+  __shared__ __attribute__((aligned(16))) float Bs[GBK][GBN + BPAD + APAD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+  const float* A = g.A + (long)blockIdx.z * g.a_zs;
+  const float* B = g.B + (long)blockIdx.z * g.b_zs;
+  float* C = g.C + (long)blockIdx.z * g.c_zs;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  for (int k0 = 0; k0 < g.K; k0 += GBK) {
+    // ---- stage A tile [GBK][GBM]
+    if (A_KC) {
+#pragma unroll
+      for (int rep = 0; rep < 2; rep++) {
+        const int m = (tid >> 2) + rep * 64, k4 = (tid & 3) * 4;
+        const int gm = m0 + m, gk = k0 + k4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gm < g.M) {
+          const float* p = A + (long)gm * g.lda + gk;
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (gk + i < g.K) v[i] = p[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) As[k4 + i][m] = v[i];
+      }
+    } else {
+#pragma unroll
+      for (int rep = 0; rep < 2; rep++) {
+        const int k = (tid >> 5) + rep * 8, m4 = (tid & 31) * 4;
+        const int gk = k0 + k, gm = m0 + m4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gk < g.K) {
+          const float* p = A + (long)gk * g.lda + gm;
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (gm + i < g.M) v[i] = p[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) As[k][m4 + i] = v[i];
+      }
+    }
+    // ---- stage B tile [GBK][GBN]
+    if (B_KC) {
+#pragma unroll
+      for (int rep = 0; rep < 2; rep++) {
+        const int n = (tid >> 2) + rep * 64, k4 = (tid & 3) * 4;
+        const int gn = n0 + n, gk = k0 + k4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gn < g.N) {
+          const float* p = B + (long)gn * g.ldb + gk;
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (gk + i < g.K) v[i] = p[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) Bs[k4 + i][n] = v[i];
+      }
+    } else {
+#pragma unroll
+      for (int rep = 0; rep < 2; rep++) {
+        const int k = (tid >> 5) + rep * 8, n4 = (tid & 31) * 4;
+        const int gk = k0 + k, gn = n0 + n4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gk < g.K) {
+          const float* p = B + (long)gk * g.ldb + gn;
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (gn + i < g.N) v[i] = p[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) Bs[k][n4 + i] = v[i];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GBK; kk += 2) {
+      const int kr = kk + (lane >> 5), c = lane & 31;
+      const float a0 = As[kr][wm * 64 + c], a1 = As[kr][wm * 64 + 32 + c];
+      const float b0 = Bs[kr][wn * 64 + c], b1 = Bs[kr][wn * 64 + 32 + c];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: accumulator element r of tile (i,j) is row (r&3)+8*(r>>2)+4*(lane>>5), column lane&31
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+      if (n >= g.N) continue;
+      const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= g.M) continue;
+        float v = acc[i][j][r] + bv;
+        long idx;
+        if (EPI == EPI_CONV) {
+          const int b = m / g.H3, h = m - b * g.H3;
+          idx = ((long)b * g.N + n) * g.H3 + h;
+        } else {
+          idx = (long)m * g.ldc + n;
+        }
+        if (g.accumulate) v += C[idx];
+        if (g.relu) v = v > 0.f ? v : 0.f;
+        if (EPI == EPI_MASK) v = g.mask[idx] > 0.f ? v : 0.f;
+        C[idx] = v;
+      }
+    }
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+static int launch_gemm(const GemmArgs& g, int nz, hipStream_t stream) {
+  dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, nz);
+  hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, EPI>), grid, dim3(256), 0, stream, g);
+  if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
+  return FLM_OK;
+}
+
+// out[n] = sum over z of part[z*n_elem + n]  (deterministic split-K reduction)
+__global__ void reduce_partials_kernel(const float* __restrict__ part, int nz, long n_elem, float* __restrict__ out) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_elem) return;
+  float s = 0.f;
+  for (int z = 0; z < nz; z++) s += part[(long)z * n_elem + i];
+  out[i] = s;
+}
+
+// column sums: out[n] = sum_m X[m*ld + n], one workgroup per 64 columns, fixed summation order
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int N, long ld, float* __restrict__ out) {
+  __shared__ float s[4][64];
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (n < N)
+    for (int m = w; m < M; m += 4) acc += X[(long)m * ld + n];
+  s[w][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (w == 0 && n < N) out[n] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+}
+
+// conv bias gradient: out[c] = sum over b,h of dX1[b][c][h]
+__global__ __launch_bounds__(256) void conv_bias_grad_kernel(const float* __restrict__ dX1, int B, int H3, float* __restrict__ out) {
+  __shared__ float s[256];
+  const int c = blockIdx.x;
+  float acc = 0.f;
+  for (long i = threadIdx.x; i < (long)B * H3; i += 256) {
+    long b = i / H3, h = i - b * H3;
+    acc += dX1[(b * 64 + c) * H3 + h];
+  }
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] = s[0];
+}
+
+// ---- small-batch first dense layer (act: B <= 8): one wave per output neuron streams its weight row
+template <int BMAX>
+__global__ __launch_bounds__(256) void fc1_small_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, int B, long K, float* __restrict__ out,
+                                                        int ldo, int n_rows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n_rows) return;
+  const float4* w4 = reinterpret_cast<const float4*>(W + (long)row * K);
+  float acc[BMAX];
+#pragma unroll
+  for (int b = 0; b < BMAX; b++) acc[b] = 0.f;
+  const long K4 = K >> 2;
+  for (long i = lane; i < K4; i += 64) {
+    const float4 w = w4[i];
+#pragma unroll
+    for (int b = 0; b < BMAX; b++)
+      if (b < B) {
+        const float4 x = reinterpret_cast<const float4*>(X + (long)b * K)[i];
+        acc[b] = fmaf(w.x, x.x, acc[b]);
+        acc[b] = fmaf(w.y, x.y, acc[b]);
+        acc[b] = fmaf(w.z, x.z, acc[b]);
+        acc[b] = fmaf(w.w, x.w, acc[b]);
+      }
+  }
+#pragma unroll
+  for (int b = 0; b < BMAX; b++) {
+    float v = acc[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if (lane == 0 && b < B) {
+      v += bias[row];
+      out[(long)b * ldo + row] = v > 0.f ? v : 0.f;
+    }
+  }
+}
+
+// ---- output layers + dueling combination, one wave per sample ------------------------------------------
+// hid[B,1024]: columns 0..511 advantage stream, 512..1023 value stream.  q[B,2].
+__global__ __launch_bounds__(64) void head_forward_kernel(const float* __restrict__ hid, const float* __restrict__ a2w,
+                                                          const float* __restrict__ a2b, const float* __restrict__ v2w,
+                                                          const float* __restrict__ v2b, int B, float* __restrict__ q) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (b >= B) return;
+  const float* h = hid + (long)b * 1024;
+  float s0 = 0.f, s1 = 0.f, sv = 0.f;
+  for (int i = lane; i < 512; i += 64) {
+    const float ha = h[i], hv = h[512 + i];
+    s0 = fmaf(ha, a2w[i], s0);
+    s1 = fmaf(ha, a2w[512 + i], s1);
+    sv = fmaf(hv, v2w[i], sv);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s0 += __shfl_down(s0, o);
+    s1 += __shfl_down(s1, o);
+    sv += __shfl_down(sv, o);
+  }
+  if (lane == 0) {
+    const float adv0 = s0 + a2b[0], adv1 = s1 + a2b[1], val = sv + v2b[0];
+    const float mean = (adv0 + adv1) * 0.5f;
+    q[b * 2 + 0] = val + adv0 - mean;
+    q[b * 2 + 1] = val + adv1 - mean;
+  }
+}
+
+// Double-DQN target and loss gradient (src/agent.py:97-111):
+//   a* = argmax_a q_next_local[b,a];  target = r + gamma * q_next_target[b,a*] * (1 - done)
+//   loss = mean_b (q[b,action[b]] - target)^2;  dq[b,a] = 2*(q - target)/B on the taken action, else 0
+__global__ void td_loss_kernel(const float* __restrict__ q, const float* __restrict__ q_next_local,
+                               const float* __restrict__ q_next_target, const int64_t* __restrict__ action,
+                               const float* __restrict__ reward, const float* __restrict__ done, float gamma, int B,
+                               float* __restrict__ dq, float* __restrict__ sq_err) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int astar = q_next_local[b * 2 + 1] > q_next_local[b * 2 + 0] ? 1 : 0;
+  const float target = reward[b] + (gamma * q_next_target[b * 2 + astar]) * (1.f - done[b]);
+  const int a = (int)action[b];
+  const float diff = q[b * 2 + a] - target;
+  sq_err[b] = diff * diff;
+  dq[b * 2 + a] = 2.f * diff / (float)B;
+  dq[b * 2 + (1 - a)] = 0.f;
+}
+
+__global__ void mean_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < n; i++) s += x[i];
+    *out = s / (float)n;
+  }
+}
+
+// Backward of the head: from dq[B,2] to the hidden-layer gradient dhid[B,1024] (ReLU applied) and the
+// gradients of the four small tensors.  One wave per sample writes dhid; the small tensors are reduced
+// by a second kernel over the batch in a fixed order.
+__global__ __launch_bounds__(64) void head_backward_hidden_kernel(const float* __restrict__ hid, const float* __restrict__ dq,
+                                                                  const float* __restrict__ a2w, const float* __restrict__ v2w,
+                                                                  int B, float* __restrict__ dhid, float* __restrict__ dadv,
+                                                                  float* __restrict__ dval) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (b >= B) return;
+  const float d0 = dq[b * 2], d1 = dq[b * 2 + 1];
+  const float dv = d0 + d1;
+  const float da0 = d0 - 0.5f * (d0 + d1), da1 = d1 - 0.5f * (d0 + d1);
+  const float* h = hid + (long)b * 1024;
+  float* dh = dhid + (long)b * 1024;
+  for (int i = lane; i < 512; i += 64) {
+    const float ga = da0 * a2w[i] + da1 * a2w[512 + i];
+    dh[i] = h[i] > 0.f ? ga : 0.f;
+    const float gv = dv * v2w[i];
+    dh[512 + i] = h[512 + i] > 0.f ? gv : 0.f;
+  }
+  if (lane == 0) {
+    dadv[b * 2] = da0;
+    dadv[b * 2 + 1] = da1;
+    dval[b] = dv;
+  }
+}
+
+// g_a2w[a,i] = sum_b dadv[b,a]*hid[b,i]; g_a2b[a] = sum_b dadv[b,a]; g_v2w[i] = sum_b dval[b]*hid[b,512+i]; g_v2b
+__global__ __launch_bounds__(256) void head_backward_params_kernel(const float* __restrict__ hid, const float* __restrict__ dadv,
+                                                                   const float* __restrict__ dval, int B,
+                                                                   float* __restrict__ g_a2w, float* __restrict__ g_a2b,
+                                                                   float* __restrict__ g_v2w, float* __restrict__ g_v2b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 512) {
+    float s0 = 0.f, s1 = 0.f, sv = 0.f;
+    for (int b = 0; b < B; b++) {
+      const float ha = hid[(long)b * 1024 + i], hv = hid[(long)b * 1024 + 512 + i];
+      s0 = fmaf(dadv[b * 2], ha, s0);
+      s1 = fmaf(dadv[b * 2 + 1], ha, s1);
+      sv = fmaf(dval[b], hv, sv);
+    }
+    g_a2w[i] = s0;
+    g_a2w[512 + i] = s1;
+    g_v2w[i] = sv;
+  }
+  if (i == 0) {
+    float s0 = 0.f, s1 = 0.f, sv = 0.f;
+    for (int b = 0; b < B; b++) {
+      s0 += dadv[b * 2];
+      s1 += dadv[b * 2 + 1];
+      sv += dval[b];
+    }
+    g_a2b[0] = s0;
+    g_a2b[1] = s1;
+    g_v2b[0] = sv;
+  }
+}
+
+// ---- optimiser and target network --------------------------------------------------------------------
+// torch.optim.Adam defaults (no weight decay, no amsgrad), one step over the flat buffers.  The products
+// are kept unfused so that every intermediate is rounded where the tensor-by-tensor formulation rounds it.
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long n, float one_minus_b1, float beta2, float one_minus_b2, float eps, float step_size,
+                            float bc2_sqrt) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  const float mi = __fadd_rn(m[i], __fmul_rn(one_minus_b1, __fsub_rn(gi, m[i])));
+  const float vi = __fadd_rn(__fmul_rn(v[i], beta2), __fmul_rn(__fmul_rn(one_minus_b2, gi), gi));
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2_sqrt), eps);
+  p[i] = __fadd_rn(p[i], __fmul_rn(-step_size, __fdiv_rn(mi, denom)));
+}
+
+// target <- tau*local + (1-tau)*target (src/agent.py:120-131)
+__global__ void soft_update_kernel(float* __restrict__ target, const float* __restrict__ local, long n, float tau,
+                                   float one_minus_tau) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  target[i] = __fadd_rn(__fmul_rn(tau, local[i]), __fmul_rn(one_minus_tau, target[i]));
+}
+
+// uint8 observation planes (own plane is int8) -> fp32 rows [n, H3=3*Rp, T1]
+__global__ void obs_to_f32_kernel(const uint8_t* __restrict__ obs, int n, int Rp, int T1, int plane_stride, float* __restrict__ out) {
+  const long total = (long)n * 3 * Rp * T1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long per = (long)Rp * T1;
+    const long s = i / (3 * per), rem = i - s * 3 * per;
+    const int pl = (int)(rem / per);
+    const long o = rem - pl * per;
+    const uint8_t u = obs[(s * 3 + pl) * plane_stride + o];
+    out[i] = pl == 0 ? (float)(int8_t)u : (float)u;
+  }
+}
+
+}  // namespace flm
+
+using flm::DqnLayout;
+using flm::GemmArgs;
+
+extern "C" long flm_dqn_param_count(int H3, int T1) { return DqnLayout(H3, T1).total; }
+
+// workspace floats needed by flm_dqn_forward for a batch of B samples
+extern "C" long flm_dqn_forward_workspace(int B, int H3) { return (long)B * 64 * H3 + (long)B * 1024; }
+
+static int dqn_forward_impl(const float* params, const float* x, int B, int H3, int T1, float* x1, float* hid, float* q,
+                            hipStream_t stream) {
+  DqnLayout L(H3, T1);
+  GemmArgs g{};
+  // conv as GEMM: rows (b,h), K = T1, 64 filters; stored as [b][c][h] with ReLU
+  g.A = x; g.B = params + L.conv_w; g.C = x1; g.bias = params + L.conv_b; g.mask = nullptr;
+  g.M = B * H3; g.N = 64; g.K = T1; g.lda = T1; g.ldb = T1; g.ldc = 0; g.a_zs = g.b_zs = g.c_zs = 0;
+  g.relu = 1; g.accumulate = 0; g.H3 = H3;
+  int rc = flm::launch_gemm<true, true, flm::EPI_CONV>(g, 1, stream);
+  if (rc) return rc;
+  if (B <= 8 && (L.K1 & 3) == 0) {
+    hipLaunchKernelGGL(flm::fc1_small_kernel<8>, dim3(128), dim3(256), 0, stream, x1, params + L.a1_w, params + L.a1_b, B,
+                       L.K1, hid, 1024, 512);
+    hipLaunchKernelGGL(flm::fc1_small_kernel<8>, dim3(128), dim3(256), 0, stream, x1, params + L.v1_w, params + L.v1_b, B,
+                       L.K1, hid + 512, 1024, 512);
+    if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
+  } else {
+    for (int s = 0; s < 2; s++) {
+      g = GemmArgs{};
+      g.A = x1; g.B = params + (s ? L.v1_w : L.a1_w); g.C = hid + s * 512; g.bias = params + (s ? L.v1_b : L.a1_b);
+      g.M = B; g.N = 512; g.K = (int)L.K1; g.lda = L.K1; g.ldb = L.K1; g.ldc = 1024; g.relu = 1;
+      rc = flm::launch_gemm<true, true, flm::EPI_PLAIN>(g, 1, stream);
+      if (rc) return rc;
+    }
+  }
+  hipLaunchKernelGGL(flm::head_forward_kernel, dim3(B), dim3(64), 0, stream, hid, params + L.a2_w, params + L.a2_b,
+                     params + L.v2_w, params + L.v2_b, B, q);
+  if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
+  return FLM_OK;
+}
+
+extern "C" int flm_dqn_forward(const float* params, const float* x, int B, int H3, int T1, float* workspace, float* q,
+                               void* stream) {
+  if (!params || !x || !workspace || !q || B <= 0 || H3 <= 0 || T1 <= 0) return FLM_E_ARG;
+  float* x1 = workspace;
+  float* hid = workspace + (long)B * 64 * H3;
+  return dqn_forward_impl(params, x, B, H3, T1, x1, hid, q, (hipStream_t)stream);
+}
+
+extern "C" int flm_obs_to_f32(const uint8_t* obs, int n, int Rp, int T1, int plane_stride, float* out, void* stream) {
+  if (!obs || !out || n <= 0 || Rp <= 0 || T1 <= 0 || (long)plane_stride < (long)Rp * T1) return FLM_E_ARG;
+  hipLaunchKernelGGL(flm::obs_to_f32_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, obs, n, Rp, T1, plane_stride,
+                     out);
+  if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
+  return FLM_OK;
+}
+
+// workspace floats needed by flm_dqn_learn_grads
+extern "C" long flm_dqn_learn_workspace(int B, int H3, int T1) {
+  const long act = (long)B * 64 * H3 + (long)B * 1024;        // x1 + hid of one forward
+  return 3 * act                                              // three forwards
+         + (long)B * 1024                                     // dhid
+         + (long)B * 64 * H3                                  // dx1
+         + (long)B * 64 * T1                                  // per-sample conv weight partials
+         + 16L * B + 64;                                      // q's, dq, dadv, dval, squared errors, loss
+}
+
+// Forward passes, loss and backward of one learn step (src/agent.py:94-114); grads gets dLoss/dparams of
+// the local network in the flat layout, loss_out the scalar mean-squared error.
+extern "C" int flm_dqn_learn_grads(const float* local, const float* target, const float* s, const float* s_next,
+                                   const int64_t* action, const float* reward, const float* done, float gamma, int B,
+                                   int H3, int T1, float* ws, float* grads, float* loss_out, void* stream_) {
+  if (!local || !target || !s || !s_next || !action || !reward || !done || !ws || !grads || !loss_out) return FLM_E_ARG;
+  if (B <= 0 || H3 <= 0 || T1 <= 0) return FLM_E_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  DqnLayout L(H3, T1);
+  const long n_x1 = (long)B * 64 * H3, n_hid = (long)B * 1024;
+  float* x1 = ws;            float* hid = x1 + n_x1;
+  float* x1n = hid + n_hid;  float* hidn = x1n + n_x1;
+  float* x1t = hidn + n_hid; float* hidt = x1t + n_x1;
+  float* dhid = hidt + n_hid;
+  float* dx1 = dhid + n_hid;
+  float* cpart = dx1 + n_x1;
+  float* q = cpart + (long)B * 64 * T1;
+  float* qn = q + 2 * B; float* qt = qn + 2 * B; float* dq = qt + 2 * B;
+  float* dadv = dq + 2 * B; float* dval = dadv + 2 * B; float* sq = dval + B;
+  int rc;
+  if ((rc = dqn_forward_impl(local, s, B, H3, T1, x1, hid, q, stream))) return rc;
+  if ((rc = dqn_forward_impl(local, s_next, B, H3, T1, x1n, hidn, qn, stream))) return rc;
+  if ((rc = dqn_forward_impl(target, s_next, B, H3, T1, x1t, hidt, qt, stream))) return rc;
+  hipLaunchKernelGGL(flm::td_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, q, qn, qt, action, reward, done, gamma,
+                     B, dq, sq);
+  hipLaunchKernelGGL(flm::mean_kernel, dim3(1), dim3(64), 0, stream, sq, B, loss_out);
+  // head
+  hipLaunchKernelGGL(flm::head_backward_hidden_kernel, dim3(B), dim3(64), 0, stream, hid, dq, local + L.a2_w, local + L.v2_w, B,
+                     dhid, dadv, dval);
+  hipLaunchKernelGGL(flm::head_backward_params_kernel, dim3(2), dim3(256), 0, stream, hid, dadv, dval, B, grads + L.a2_w,
+                     grads + L.a2_b, grads + L.v2_w, grads + L.v2_b);
+  if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
+  // first dense layer: weight gradients dW[n,j] = sum_b dhid[b,n] * x1[b,j]; bias gradients = column sums
+  for (int st = 0; st < 2; st++) {
+    GemmArgs g{};
+    g.A = dhid + st * 512; g.B = x1; g.C = grads + (st ? L.v1_w : L.a1_w);
+    g.M = 512; g.N = (int)L.K1; g.K = B; g.lda = 1024; g.ldb = L.K1; g.ldc = L.K1;
+    if ((rc = flm::launch_gemm<false, false, flm::EPI_PLAIN>(g, 1, stream))) return rc;
+    hipLaunchKernelGGL(flm::colsum_kernel, dim3(8), dim3(256), 0, stream, dhid + st * 512, B, 512, 1024L,
+                       grads + (st ? L.v1_b : L.a1_b));
+  }
+  // gradient w.r.t. the conv activations: dx1 = dhid_adv * W_adv + dhid_val * W_val, zero where x1 == 0
+  for (int st = 0; st < 2; st++) {
+    GemmArgs g{};
+    g.A = dhid + st * 512; g.B = local + (st ? L.v1_w : L.a1_w); g.C = dx1; g.mask = x1;
+    g.M = B; g.N = (int)L.K1; g.K = 512; g.lda = 1024; g.ldb = L.K1; g.ldc = L.K1; g.accumulate = st;
+    if (st == 0) rc = flm::launch_gemm<true, false, flm::EPI_PLAIN>(g, 1, stream);
+    else rc = flm::launch_gemm<true, false, flm::EPI_MASK>(g, 1, stream);
+    if (rc) return rc;
+  }
+  // conv weights: per sample dWc_b[64,T1] = dx1_b[64,H3] * s_b[H3,T1], then a fixed-order sum over the batch
+  {
+    GemmArgs g{};
+    g.A = dx1; g.B = s; g.C = cpart;
+    g.M = 64; g.N = T1; g.K = H3; g.lda = H3; g.ldb = T1; g.ldc = T1;
+    g.a_zs = 64L * H3; g.b_zs = (long)H3 * T1; g.c_zs = 64L * T1;
+    if ((rc = flm::launch_gemm<true, false, flm::EPI_PLAIN>(g, B, stream))) return rc;
+    const long ne = 64L * T1;
+    hipLaunchKernelGGL(flm::reduce_partials_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream, cpart, B, ne,
+                       grads + L.conv_w);
+    hipLaunchKernelGGL(flm::conv_bias_grad_kernel, dim3(64), dim3(256), 0, stream, dx1, B, H3, grads + L.conv_b);
+  }
+  if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
+  return FLM_OK;
+}
+
+extern "C" int flm_dqn_adam(float* params, const float* grads, float* m, float* v, long n, double lr, double beta1,
+                            double beta2, double eps, int step, void* stream) {
+  if (!params || !grads || !m || !v || n <= 0 || step <= 0) return FLM_E_ARG;
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  hipLaunchKernelGGL(flm::adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads, m,
+                     v, n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)(lr / bc1),
+                     (float)sqrt(bc2));
+  if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
+  return FLM_OK;
+}
+
+extern "C" int flm_dqn_soft_update(float* target, const float* local, long n, double tau, void* stream) {
+  if (!target || !local || n <= 0) return FLM_E_ARG;
+  hipLaunchKernelGGL(flm::soft_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, target,
+                     local, n, (float)tau, (float)(1.0 - tau));
+  if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
+  return FLM_OK;
+}

@@ -1,0 +1,79 @@
+"""Drop-in for the reference's Dueling_DQN (src/model.py:11-43): same constructor, same state_dict keys
+and shapes, same default initialisation; forward runs the hand-written fp32 MFMA kernels (no autograd)."""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import call, ptr, query
+
+
+class Dueling_DQN(nn.Module):
+    def __init__(self, width, height, action_space):
+        super(Dueling_DQN, self).__init__()
+        if action_space != 2:
+            raise ValueError("the device kernels implement the reference's two actions (stop/go)")
+        self.action_space = action_space
+        self.width, self.height = int(width), int(height)
+        # same submodules in the same order as the reference => identical default init and state_dict keys
+        self.conv1 = nn.Conv2d(in_channels=1, out_channels=64, kernel_size=(1, width))
+        self.fc1_adv = nn.Linear(in_features=64 * height, out_features=512)
+        self.fc1_val = nn.Linear(in_features=64 * height, out_features=512)
+        self.fc2_adv = nn.Linear(in_features=512, out_features=action_space)
+        self.fc2_val = nn.Linear(in_features=512, out_features=1)
+        self.relu = nn.ReLU()
+        self._flat = None
+        self._ws = {}
+
+    # ---- flat parameter buffer -------------------------------------------------------------------------
+    def flat_params(self):
+        """One contiguous fp32 device buffer; the module's parameters are views into it."""
+        params = list(self.parameters())
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise _lib.FlmError("Dueling_DQN must live on a GPU (call .to('cuda')): there is no CPU forward")
+        ok = self._flat is not None and self._flat.device == dev
+        if ok:
+            off = 0
+            base = self._flat.data_ptr()
+            for p in params:
+                if p.data_ptr() != base + 4 * off:
+                    ok = False
+                    break
+                off += p.numel()
+        if not ok:
+            n = sum(p.numel() for p in params)
+            assert n == query("flm_dqn_param_count", self.height, self.width)
+            flat = torch.empty(n, dtype=torch.float32, device=dev)
+            off = 0
+            for p in params:
+                flat[off:off + p.numel()].copy_(p.data.reshape(-1).float())
+                p.data = flat[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+            self._flat = flat
+        return self._flat
+
+    def __deepcopy__(self, memo):
+        new = Dueling_DQN(self.width, self.height, self.action_space)
+        new.load_state_dict(self.state_dict())
+        dev = next(self.parameters()).device
+        new.to(dev)
+        new.train(self.training)
+        return new
+
+    def _workspace(self, B):
+        dev = self._flat.device
+        ws = self._ws.get(B)
+        if ws is None or ws.device != dev:
+            ws = torch.empty(query("flm_dqn_forward_workspace", B, self.height), dtype=torch.float32, device=dev)
+            self._ws = {B: ws}
+        return ws
+
+    def forward(self, x):
+        flat = self.flat_params()
+        x = x.to(device=flat.device, dtype=torch.float32).contiguous()
+        B = x.size(0)
+        x = x.view(B, self.height, self.width)
+        q = torch.empty((B, 2), dtype=torch.float32, device=flat.device)
+        call("flm_dqn_forward", ptr(flat), ptr(x), B, self.height, self.width, ptr(self._workspace(B)), ptr(q),
+             torch.cuda.current_stream(flat.device).cuda_stream)
+        return q

@@ -164,6 +164,39 @@ int flm_check_crash(const int8_t* maps, const int32_t* status, const int32_t* tp
 int flm_update_bitmaps(int8_t* maps, const int32_t* status, const int32_t* tpc, const int32_t* agent_sel,
                        const int32_t* before_switch, int E, int A, int Rp, int T1, int plane_stride, void* stream);
 
+/* ---- Dueling Double-DQN (fp32; matrix products on the fp32 MFMA) -------------------------------------
+ * Replaces Dueling_DQN.forward, src/model.py:31-43, and the numeric part of DQNAgent.act / learn /
+ * soft_update, src/agent.py:69-131.  H3 = 3*max_rails input rows, T1 = depth+1 columns, 2 actions.
+ * Parameters are one flat float buffer in the order of the module's parameters():
+ *   conv1.weight[64,T1] conv1.bias[64] fc1_adv.weight[512,64*H3] fc1_adv.bias[512] fc1_val.weight[512,64*H3]
+ *   fc1_val.bias[512] fc2_adv.weight[2,512] fc2_adv.bias[2] fc2_val.weight[1,512] fc2_val.bias[1]. */
+long flm_dqn_param_count(int H3, int T1);
+long flm_dqn_forward_workspace(int B, int H3);              /* floats */
+long flm_dqn_learn_workspace(int B, int H3, int T1);        /* floats */
+
+/* q[B,2] = network(x[B,H3,T1]).  workspace: flm_dqn_forward_workspace(B,H3) floats. */
+int flm_dqn_forward(const float* params, const float* x, int B, int H3, int T1, float* workspace, float* q,
+                    void* stream);
+
+/* uint8 observations [n,3,plane_stride] (own plane int8) -> float rows [n,3*Rp,T1], the network's input. */
+int flm_obs_to_f32(const uint8_t* obs, int n, int Rp, int T1, int plane_stride, float* out, void* stream);
+
+/* One learn step up to the gradient (src/agent.py:94-114, double DQN): three forward passes, the
+ * mean-squared TD error (loss_out[1]) and its gradient w.r.t. the local network (grads, flat layout).
+ * action int64 [B], reward/done float [B].  workspace: flm_dqn_learn_workspace floats.
+ * The reference also back-propagates into the target network (its Q_targets are not detached); those
+ * gradients are never used by the optimizer and are not computed here. */
+int flm_dqn_learn_grads(const float* local, const float* target, const float* s, const float* s_next,
+                        const int64_t* action, const float* reward, const float* done, float gamma, int B, int H3,
+                        int T1, float* workspace, float* grads, float* loss_out, void* stream);
+
+/* torch.optim.Adam step with default options over flat buffers (src/agent.py:38,113-115); step counts from 1. */
+int flm_dqn_adam(float* params, const float* grads, float* m, float* v, long n, double lr, double beta1, double beta2,
+                 double eps, int step, void* stream);
+
+/* target <- tau*local + (1-tau)*target, src/agent.py:120-131. */
+int flm_dqn_soft_update(float* target, const float* local, long n, double tau, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared():
     text = open(os.path.join(ROOT, "include", "flmarl.h")).read()
-    return sorted(set(re.findall(r"^(?:int|const char\*)\s+(flm_\w+)\s*\(", text, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|long|const char\*)\s+(flm_\w+)\s*\(", text, flags=re.M)))
 
 
 def test_header_declares_symbols():

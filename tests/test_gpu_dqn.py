@@ -1,0 +1,132 @@
+"""Dueling Double-DQN kernels: against the reference's goldens and a plain PyTorch fp32 checker (needs an MI355X).
+
+Tolerance (stated by the task for this floating-point path): Q-values within 1e-5 relative in fp32; values
+close to zero are judged against the largest |Q| of the batch."""
+import argparse
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import GOLDEN
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def close(got, want, scale=None, rtol=RTOL):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    scale = np.abs(want).max() if scale is None else scale
+    return np.all(np.abs(got - want) <= rtol * np.maximum(np.abs(want), scale))
+
+
+def tensor_sums(flat, shapes):
+    out, off = [], 0
+    for shp in shapes:
+        n = int(np.prod(shp))
+        t = flat[off:off + n].double()
+        out.append([float(t.sum()), float(t.abs().sum())])
+        off += n
+    return np.array(out)
+
+
+def test_forward_matches_reference_golden():
+    from tests import dqn_inputs
+    from flatland_marl_amd.model import Dueling_DQN
+    gold = dict(np.load(os.path.join(GOLDEN, "dqn_reference.npz")))
+    H3, T1 = 3 * dqn_inputs.MAX_RAILS, dqn_inputs.DEPTH + 1
+    torch.manual_seed(1234)
+    net = Dueling_DQN(T1, H3, 2)
+    sums = np.array([[float(p.double().sum()), float(p.double().abs().sum())] for p in net.parameters()])
+    assert np.array_equal(sums, gold["act_param_sums"])          # same default init as the reference
+    assert [tuple(v.shape) for v in net.state_dict().values()] == [
+        (64, 1, 1, T1), (64,), (512, 64 * H3), (512,), (512, 64 * H3), (512,), (2, 512), (2,), (1, 512), (1,)]
+    assert list(net.state_dict()) == ["conv1.weight", "conv1.bias", "fc1_adv.weight", "fc1_adv.bias", "fc1_val.weight",
+                                      "fc1_val.bias", "fc2_adv.weight", "fc2_adv.bias", "fc2_val.weight", "fc2_val.bias"]
+    net = net.to("cuda")
+    x = torch.from_numpy(dqn_inputs.observations(6))[:, None]
+    q = net(x).cpu().numpy()
+    assert close(q, gold["act_q64"])
+    assert close(q, gold["act_q32"])
+    # one observation at a time (the act path: batch 1)
+    for i in range(6):
+        qi = net(x[i:i + 1]).cpu().numpy()
+        assert close(qi, gold["act_q64"][i:i + 1], scale=np.abs(gold["act_q64"]).max())
+
+
+def _args(B):
+    from tests import dqn_inputs
+    return argparse.Namespace(prediction_depth=dqn_inputs.DEPTH, lr=0.00005, buffer_size=100, batch_size=B,
+                              update_every=10, gamma=0.99, tau=1e-3)
+
+
+def test_learn_matches_reference_golden():
+    from tests import dqn_inputs
+    from flatland_marl_amd.agent import DQNAgent
+    gold = dict(np.load(os.path.join(GOLDEN, "dqn_reference.npz")))
+    H3 = 3 * dqn_inputs.MAX_RAILS
+    B = 16
+    torch.manual_seed(4321)
+    agent = DQNAgent(_args(B), action_space=2, bitmap_height=H3)
+    s, a, r, sn, d = dqn_inputs.learn_batch(B)
+    st, snt = torch.from_numpy(s)[:, None], torch.from_numpy(sn)[:, None]
+    assert close(agent.qnetwork_local(st).cpu().numpy(), gold["learn_q_before"])
+    exp = (st, torch.from_numpy(a), torch.from_numpy(r), snt, torch.from_numpy(d.astype(np.uint8)).float())
+    agent.learn(exp, 0.99)
+    shapes = [tuple(p.shape) for p in agent.qnetwork_local.parameters()]
+    gs = tensor_sums(agent.optimizer.grads, shapes)
+    assert close(gs[:, 1], gold["learn_grad_sums"][:, 1], rtol=1e-5)          # sum of |grad| per tensor
+    assert close(gs[:, 0], gold["learn_grad_sums"][:, 0], scale=np.abs(gold["learn_grad_sums"][:, 1]).max() * 1e-2,
+                 rtol=1e-4)
+    assert close(agent.qnetwork_local(st).cpu().numpy(), gold["learn_q_local_after"])
+    assert close(agent.qnetwork_target(st).cpu().numpy(), gold["learn_q_target_after"])
+    assert close(tensor_sums(agent.qnetwork_local.flat_params(), shapes)[:, 1], gold["learn_local_sums"][:, 1], rtol=1e-6)
+    assert close(tensor_sums(agent.qnetwork_target.flat_params(), shapes)[:, 1], gold["learn_target_sums"][:, 1], rtol=1e-6)
+    agent.learn(exp, 0.99)
+    assert close(agent.qnetwork_local(st).cpu().numpy(), gold["learn2_q_local_after"])
+    assert close(tensor_sums(agent.qnetwork_local.flat_params(), shapes)[:, 1], gold["learn2_local_sums"][:, 1], rtol=1e-6)
+
+
+@pytest.mark.parametrize("B,H3,T1", [(3, 30, 21), (40, 30, 21), (130, 9, 151), (64, 60, 37)])
+def test_gradients_elementwise_vs_torch(B, H3, T1):
+    """Every gradient element, the loss, the Adam step and the soft update against plain PyTorch fp32."""
+    from flatland_marl_amd.agent import DQNAgent
+    from tests.torch_ref_dqn import TorchDuelingDQN, learn_step
+    torch.manual_seed(7 + B)
+    args = argparse.Namespace(prediction_depth=T1 - 1, lr=0.001, buffer_size=10, batch_size=B, update_every=1,
+                              gamma=0.9, tau=0.05)
+    agent = DQNAgent(args, action_space=2, bitmap_height=H3)
+    ref_local = TorchDuelingDQN(T1, H3)
+    ref_local.load_state_dict(agent.qnetwork_local.state_dict())
+    ref_target = copy.deepcopy(ref_local)
+    # make the target differ from the local network
+    with torch.no_grad():
+        for p in ref_target.parameters():
+            p.mul_(0.9)
+    agent.qnetwork_target.load_state_dict(ref_target.state_dict())
+    opt = torch.optim.Adam(ref_local.parameters(), lr=args.lr)
+    g = torch.Generator().manual_seed(B)
+    s = torch.randint(-1, 4, (B, 1, H3, T1), generator=g).float()
+    sn = torch.randint(-1, 4, (B, 1, H3, T1), generator=g).float()
+    a = torch.randint(0, 2, (B,), generator=g)
+    r = torch.randn(B, generator=g)
+    d = (torch.rand(B, generator=g) < 0.3).float()
+    for it in range(2):
+        q_ref = ref_local(s).detach().numpy()
+        assert close(agent.qnetwork_local(s).cpu().numpy(), q_ref)
+        loss = learn_step(ref_local, ref_target, opt, (s, a, r, sn, d), args.gamma, args.tau)
+        agent.learn((s, a, r, sn, d), args.gamma)
+        assert close(agent.last_loss.cpu().numpy(), loss.detach().numpy())
+        off = 0
+        flat_g = agent.optimizer.grads.cpu().numpy()
+        for p in ref_local.parameters():
+            n = p.numel()
+            got, want = flat_g[off:off + n], p.grad.reshape(-1).numpy()
+            assert close(got, want, rtol=2e-5), (it, off)
+            off += n
+        for mine, ref in ((agent.qnetwork_local, ref_local), (agent.qnetwork_target, ref_target)):
+            got = mine.flat_params().cpu().numpy()
+            want = np.concatenate([p.detach().reshape(-1).numpy() for p in ref.parameters()])
+            assert close(got, want, rtol=2e-5)
