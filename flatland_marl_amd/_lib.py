@@ -23,6 +23,9 @@ _SIGNATURES = {
     "flm_graph_build": [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "flm_state_index": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p],
     "flm_distance_bfs": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p],
+    "flm_target_slots": [_p, _i, _i, _p, _p, _p, _p],
+    "flm_chain_index": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
+    "flm_distance_chains": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     "flm_shortest_paths": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     "flm_bitmaps": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     "flm_observations": [_p, _p, _i, _i, _i, _p, _p],

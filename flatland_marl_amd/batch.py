@@ -60,7 +60,7 @@ class ObservationBatch:
         self.cap_cells = int((grid != 0).reshape(self.E, -1).sum(1).max())
         if self.cap_cells * 4 >= 65535:
             raise ValueError("more than 16383 rail cells per environment are not supported")
-        self.cap_cells = max(self.cap_cells, 1)
+        self.cap_cells = max(self.cap_cells + (self.cap_cells & 1), 2)   # even: distance rows stay 16-byte aligned
         self.R = None
         self.maps = None
         self.obs = None
@@ -133,17 +133,49 @@ class ObservationBatch:
             raise _lib.FlmError("graph capacities exceeded in an asynchronous build")
 
     # ------------------------------------------------------------------ distances and paths
-    def compute_distances(self):
+    def compute_distances(self, method=None):
+        """Distance of every (rail cell, heading) state to every distinct target of every environment.
+
+        method "chains" (default when the tables fit in LDS) or "bfs" (wave-per-target breadth-first search)."""
         E, A, dev = self.E, self.A, self.device
         i32 = dict(dtype=torch.int32, device=dev)
+        s = self.stream.cuda_stream
+        capS = self.cap_cells * 4
         if getattr(self, "dist", None) is None:
             self.tslot = torch.empty((E, A), **i32)
             self.n_slots = torch.empty((E,), **i32)
             self.slot_target = torch.empty((E, A), **i32)
-            self.dist = torch.empty((E, A, self.cap_cells * 4), dtype=torch.int16, device=dev)
-        call("flm_distance_bfs", ptr(self.pred), ptr(self.cell_idx), ptr(self.n_cells), ptr(self.target_cell), E, A,
-             self.H, self.W, self.cap_cells, ptr(self.tslot), ptr(self.n_slots), ptr(self.slot_target), ptr(self.dist),
-             self.stream.cuda_stream)
+            self.dist = torch.empty((E, A, capS), dtype=torch.int16, device=dev)
+        if method is None:
+            method = "chains" if capS * 10 + capS // 8 + 512 <= 159 * 1024 else "bfs"
+        if method == "bfs":
+            call("flm_distance_bfs", ptr(self.pred), ptr(self.cell_idx), ptr(self.n_cells), ptr(self.target_cell), E,
+                 A, self.H, self.W, self.cap_cells, ptr(self.tslot), ptr(self.n_slots), ptr(self.slot_target),
+                 ptr(self.dist), s)
+            return self
+        if getattr(self, "chain_root", None) is None:
+            # anchors: states with a choice (at most two per switch cell and heading pair) + target-cell states
+            self.cap_anchor = int(min(0xFFF0, 4 * self.capN + 4 * A + 16))
+            self.chain_root = torch.empty((E, capS), dtype=torch.int16, device=dev)
+            self.chain_steps = torch.empty((E, capS), dtype=torch.int16, device=dev)
+            self.chain_edges = torch.empty((E, self.cap_anchor, 4), **i32)
+            self.n_anchor = torch.empty((E,), **i32)
+        call("flm_target_slots", ptr(self.target_cell), E, A, ptr(self.tslot), ptr(self.n_slots), ptr(self.slot_target), s)
+        call("flm_chain_index", ptr(self.grid), ptr(self.cell_idx), ptr(self.n_cells), ptr(self.target_cell), E, A,
+             self.H, self.W, self.cap_cells, self.cap_anchor, ptr(self.chain_root), ptr(self.chain_steps),
+             ptr(self.chain_edges), ptr(self.n_anchor), ptr(self.counts), s)
+        if getattr(self, "lds_anchor", None) is None:
+            # anchors = states with a choice of moves (fixed by the grid) + states on target cells (<= 4*A).
+            # The LDS tables are sized for the count seen now plus a margin for later target assignments;
+            # an environment that outgrows it is flagged in counts (check_graph) and this size is recomputed.
+            n_now = int(self.n_anchor.max().item())
+            fit = (159 * 1024 - 3 * 2048 * 2 - 64) // 100
+            self.lds_anchor = int(min(self.cap_anchor, n_now + min(4 * A, 64), max(fit, 1), 2047))
+            if self.lds_anchor < n_now:
+                return self.compute_distances(method="bfs")
+        call("flm_distance_chains", ptr(self.chain_root), ptr(self.chain_steps), ptr(self.chain_edges),
+             ptr(self.n_anchor), ptr(self.n_cells), ptr(self.cell_idx), ptr(self.slot_target), ptr(self.n_slots), E, A,
+             self.H, self.W, self.cap_cells, self.cap_anchor, self.lds_anchor, ptr(self.dist), ptr(self.counts), s)
         return self
 
     def shortest_paths(self, max_depth=None, start_cell=None, start_dir=None):

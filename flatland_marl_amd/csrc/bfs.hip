@@ -299,6 +299,15 @@ extern "C" int flm_distance_bfs(const uint16_t* pred, const int32_t* cell_idx, c
   return FLM_OK;
 }
 
+extern "C" int flm_target_slots(const int32_t* target_cell, int E, int A, int32_t* tslot, int32_t* n_slots,
+                                int32_t* slot_target, void* stream) {
+  if (!target_cell || !tslot || !n_slots || !slot_target || E <= 0 || A <= 0 || A > 8192) return FLM_E_ARG;
+  hipLaunchKernelGGL(flm::target_slots_kernel, dim3(E), dim3(256), sizeof(int) * 2 * (size_t)A, (hipStream_t)stream,
+                     target_cell, A, tslot, n_slots, slot_target);
+  FLM_CHECK_LAUNCH();
+  return FLM_OK;
+}
+
 extern "C" int flm_shortest_paths(const uint16_t* grid, const int32_t* cell_idx, const uint16_t* dist,
                                   const int32_t* tslot, const int32_t* start_cell, const int32_t* start_dir,
                                   const int32_t* target_cell, const int32_t* status, int E, int A, int H, int W,

@@ -86,6 +86,29 @@ int flm_distance_bfs(const uint16_t* pred, const int32_t* cell_idx, const int32_
                      const int32_t* target_cell, int E, int A, int H, int W, int capCells, int32_t* tslot,
                      int32_t* n_slots, int32_t* slot_target, uint16_t* dist, void* stream);
 
+/* The same distance maps computed by chain compression (the default; flm_distance_bfs is the fallback for
+ * grids whose state tables do not fit the 160 KB LDS).  Three calls:
+ *   flm_target_slots   numbers the distinct targets of every environment: tslot [E,A], n_slots [E],
+ *                      slot_target [E,A] out;
+ *   flm_chain_index    per environment: root [E,capCells*4] uint16 = number of the anchor state (a state
+ *                      with a choice of moves, or on a target cell) each state runs into, 0xFFFF = none;
+ *                      steps [E,capCells*4] uint16 = moves to get there; edges [E,capAnch,4] uint32 =
+ *                      anchor | weight<<16 per move of an anchor; n_anchor [E]; sets FLM_GRAPH_ERR_STATES
+ *                      in counts[e*4+3] when capAnch is too small.  Needs cell_idx/n_cells of
+ *                      flm_state_index and the agents' target cells;
+ *   flm_distance_chains  dist [E,A,capCells*4] as flm_distance_bfs; ldsAnch <= capAnch is the number of
+ *                      anchors the workgroup's LDS tables are sized for (80 bytes each); an environment
+ *                      with more anchors is flagged in counts[e*4+3] and its rows are left unwritten. */
+int flm_target_slots(const int32_t* target_cell, int E, int A, int32_t* tslot, int32_t* n_slots, int32_t* slot_target,
+                     void* stream);
+int flm_chain_index(const uint16_t* grid, const int32_t* cell_idx, const int32_t* n_cells, const int32_t* target_cell,
+                    int E, int A, int H, int W, int capCells, int capAnch, uint16_t* root, uint16_t* steps,
+                    uint32_t* edges, int32_t* n_anchor, int32_t* counts, void* stream);
+int flm_distance_chains(const uint16_t* root, const uint16_t* steps, const uint32_t* edges, const int32_t* n_anchor,
+                        const int32_t* n_cells, const int32_t* cell_idx, const int32_t* slot_target,
+                        const int32_t* n_slots, int E, int A, int H, int W, int capCells, int capAnch, int ldsAnch,
+                        uint16_t* dist, int32_t* counts, void* stream);
+
 /* Greedy descent on the distance map, ties broken left, forward, right.
  * Replaces get_shortest_paths, src/utils/shortest_path.py:11-90.
  *   start_cell/start_dir [E,A] int32: the position chosen at :38-49; status [E,A] int32

@@ -53,11 +53,19 @@ def main():
     if "graph" in stages:
         out["graph_ms"] = timed(lambda: b.build_graph(sync=False))
     if "bfs" in stages:
-        for v in [int(x) for x in args.bfs_variants.split(",")]:
-            _lib.call("flm_dev_set_option", 1, v)
-            out["bfs_ms_v%d" % v] = timed(b.compute_distances)
-            out["bfs_equal_v%d" % v] = bool(torch.equal(b.dist, ref_dist))
-        _lib.call("flm_dev_set_option", 1, 0)
+        for m in ("chains", "bfs"):
+            out["dist_ms_" + m] = timed(lambda: b.compute_distances(method=m))
+            out["dist_equal_" + m] = bool(torch.equal(b.dist, ref_dist))
+        for dbg in (1, 2, 3, 4, 8):
+            _lib.call("flm_dev_set_option", 2, dbg)
+            out["dist_ms_chains_dbg%d" % dbg] = timed(lambda: b.compute_distances(method="chains"))[0]
+        _lib.call("flm_dev_set_option", 2, 16)
+        b.compute_distances(method="chains")
+        rounds = b.counts[:, 2].float()
+        out["rounds_mean_max"] = [float(rounds.mean()), float(rounds.max())]
+        out["n_anchor_mean_max"] = [float(b.n_anchor.float().mean()), float(b.n_anchor.max()), b.lds_anchor]
+        _lib.call("flm_dev_set_option", 2, 0)
+        b.compute_distances()
     if "paths" in stages:
         out["paths_ms"] = timed(b.shortest_paths)
     if "bitmaps" in stages:
