@@ -116,6 +116,16 @@ class ObservationBatch:
             self._alloc_graph(self.capN, max(self.capR, int(counts[:, 1].max())), max(self.capC, int(counts[:, 2].max())))
         else:
             raise _lib.FlmError("graph build did not converge")
+        if not getattr(self, "_tight", False):
+            # shrink the capacities to what the grids need (plus a margin): the port tables of the graph
+            # kernel live in LDS, and a small node capacity lets it stage the grid there as well
+            self._tight = True
+            capN = int(counts[:, 0].max()) + 16
+            if capN < self.capN:
+                self._alloc_graph(capN, int(counts[:, 1].max()) + 16, int(counts[:, 2].max()) + 64)
+                self._launch_graph()
+                counts = self.counts.cpu().numpy()
+                assert int(np.bitwise_or.reduce(counts[:, 3])) == 0
         self.num_nodes = counts[:, 0].copy()
         self.R = counts[:, 1].copy()
         need = int(self.R.max())

@@ -20,9 +20,9 @@ struct Walk {
 
 // Follows the rail leaving cell `cell` towards heading `dir` until a node is met.
 // EMIT: also writes the cells (cell*4+heading) to out[] and lowers cell_rail[] to `rail`.
-template <bool EMIT>
-__device__ Walk walk_rail(const uint16_t* __restrict__ grid, const int32_t* __restrict__ node_id, int H, int W,
-                          int cell, int dir, int32_t* out, int out_cap, int32_t* cell_rail, int rail) {
+template <bool EMIT, typename NodeT>
+__device__ Walk walk_rail(const uint16_t* grid, const NodeT* node_id, int H, int W, int cell, int dir, int32_t* out,
+                          int out_cap, int32_t* cell_rail, int rail) {
   Walk w;
   w.end_port = -1;
   w.len = 0;
@@ -55,6 +55,9 @@ __device__ Walk walk_rail(const uint16_t* __restrict__ grid, const int32_t* __re
   return w;
 }
 
+// LDS_GRID: the transition codes and the node numbers of the environment are staged in LDS (2 + 2 bytes per
+// cell), so that the rail walks, chains of dependent look-ups, run at LDS latency.
+template <bool LDS_GRID>
 __global__ __launch_bounds__(256) void graph_build_kernel(
     const uint16_t* __restrict__ grid_all, int H, int W, int capN, int capR, int capC, int32_t* __restrict__ node_id_all,
     int32_t* __restrict__ node_cell_all, int32_t* __restrict__ edge_info_all, int32_t* __restrict__ edge_cell_off_all,
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(256) void graph_build_kernel(
   extern __shared__ __attribute__((aligned(16))) int lds[];
   const int e = blockIdx.x;
   const int HW = H * W;
-  const uint16_t* grid = grid_all + (size_t)e * HW;
+  const uint16_t* grid_g = grid_all + (size_t)e * HW;
   int32_t* node_id = node_id_all + (size_t)e * HW;
   int32_t* node_cell = node_cell_all + (size_t)e * capN;
   int32_t* edge_info = edge_info_all + (size_t)e * capR * 5;
@@ -76,6 +79,9 @@ __global__ __launch_bounds__(256) void graph_build_kernel(
   int* p_len = p_end + 4 * capN;      // [4*capN]
   int* p_first = p_len + 4 * capN;    // [4*capN]
   int* conn = p_first + 4 * capN;     // [capN] connection mask per node
+  uint16_t* l_code = reinterpret_cast<uint16_t*>(conn + capN);   // [HW] when LDS_GRID
+  int16_t* l_node = reinterpret_cast<int16_t*>(l_code + HW);     // [HW] when LDS_GRID
+  const uint16_t* grid = LDS_GRID ? l_code : grid_g;
   const int tid = threadIdx.x;
   int err = 0;
 
@@ -86,7 +92,8 @@ __global__ __launch_bounds__(256) void graph_build_kernel(
     bool is_node = false;
     int mask = 0;
     if (cell < HW) {
-      unsigned code = grid[cell];
+      unsigned code = grid_g[cell];
+      if (LDS_GRID) l_code[cell] = (uint16_t)code;
       if (code == 0x8421u) {
         is_node = true;
         mask = 0xF;
@@ -105,7 +112,10 @@ __global__ __launch_bounds__(256) void graph_build_kernel(
     }
     int tot;
     int id = n_nodes + block_flag_scan256(is_node, scratch, &tot);
-    if (cell < HW) node_id[cell] = (is_node && id < capN) ? id : -1;
+    if (cell < HW) {
+      node_id[cell] = (is_node && id < capN) ? id : -1;
+      if (LDS_GRID) l_node[cell] = (int16_t)((is_node && id < capN) ? id : -1);
+    }
     if (is_node && id < capN) {
       node_cell[id] = cell;
       conn[id] = mask;
@@ -126,7 +136,8 @@ __global__ __launch_bounds__(256) void graph_build_kernel(
     p_len[p] = 0;
     int n = p >> 2, cp = p & 3;
     if ((conn[n] >> cp) & 1) {
-      Walk w = walk_rail<false>(grid, node_id, H, W, node_cell[n], cp, nullptr, 0, nullptr, 0);
+      Walk w = LDS_GRID ? walk_rail<false>(grid, l_node, H, W, node_cell[n], cp, nullptr, 0, nullptr, 0)
+                        : walk_rail<false>(grid, node_id, H, W, node_cell[n], cp, nullptr, 0, nullptr, 0);
       p_end[p] = w.end_port;
       p_len[p] = w.len;
     }
@@ -166,7 +177,10 @@ __global__ __launch_bounds__(256) void graph_build_kernel(
       ei[4] = len;
       edge_cell_off[id] = off;
       int room = capC - off;
-      walk_rail<true>(grid, node_id, H, W, node_cell[p >> 2], p & 3, edge_cells + off, room < 0 ? 0 : room, cell_rail, id);
+      if (LDS_GRID)
+        walk_rail<true>(grid, l_node, H, W, node_cell[p >> 2], p & 3, edge_cells + off, room < 0 ? 0 : room, cell_rail, id);
+      else
+        walk_rail<true>(grid, node_id, H, W, node_cell[p >> 2], p & 3, edge_cells + off, room < 0 ? 0 : room, cell_rail, id);
     }
     n_edges += tot_e;
     n_cells += tot_c;
@@ -239,9 +253,21 @@ extern "C" int flm_graph_build(const uint16_t* grid, int E, int H, int W, int ca
   if (!grid || !node_id || !node_cell || !edge_info || !edge_cell_off || !edge_cells || !cell_rail || !counts)
     return FLM_E_ARG;
   if (E <= 0 || H <= 0 || W <= 0 || capN <= 0 || capN > FLM_MAX_NODES || capR <= 0 || capC <= 0) return FLM_E_ARG;
-  size_t lds = sizeof(int) * (8 + (size_t)capN * 13);
-  hipLaunchKernelGGL(flm::graph_build_kernel, dim3(E), dim3(256), lds, (hipStream_t)stream, grid, H, W, capN, capR,
-                     capC, node_id, node_cell, edge_info, edge_cell_off, edge_cells, cell_rail, counts);
+  const size_t lds_ports = sizeof(int) * (8 + (size_t)capN * 13);
+  const size_t lds_grid = lds_ports + 4 * (size_t)H * W;
+  // stage the grid in LDS when two workgroups still fit a CU (80 KB each)
+  const bool staged = lds_grid <= 80 * 1024;
+  const size_t lds = staged ? lds_grid : lds_ports;
+  const void* fn = staged ? reinterpret_cast<const void*>(flm::graph_build_kernel<true>)
+                          : reinterpret_cast<const void*>(flm::graph_build_kernel<false>);
+  if (lds > 160 * 1024 - 512) return FLM_E_ARG;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return FLM_E_LAUNCH;
+  if (staged)
+    hipLaunchKernelGGL(flm::graph_build_kernel<true>, dim3(E), dim3(256), lds, (hipStream_t)stream, grid, H, W, capN, capR,
+                       capC, node_id, node_cell, edge_info, edge_cell_off, edge_cells, cell_rail, counts);
+  else
+    hipLaunchKernelGGL(flm::graph_build_kernel<false>, dim3(E), dim3(256), lds, (hipStream_t)stream, grid, H, W, capN, capR,
+                       capC, node_id, node_cell, edge_info, edge_cell_off, edge_cells, cell_rail, counts);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }
