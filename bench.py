@@ -3,9 +3,9 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg5] [--envs E]
 
 One step = one pass of the whole path over one resident batch of environments:
-switch-graph build -> state numbering -> distance BFS per distinct target ->
-greedy shortest paths -> occupancy planes -> observations (own plane + two heat
-planes for every agent).  Inputs (grids, agent states) are in HBM before the
+switch-graph build -> state numbering -> distance maps per distinct target ->
+greedy shortest paths -> occupancy in column form -> observations (own plane +
+two heat planes for every agent; the own plane is the dense occupancy plane).  Inputs (grids, agent states) are in HBM before the
 timed region; nothing is copied to the host inside it.  With N > 1 every rank
 runs its own shard of environments (no collective on the data path), so the
 scaling is weak: per-GPU work is fixed.
@@ -91,15 +91,17 @@ def main():
     data = make_batch(load_fixtures(names), E, A, seed=1000003 * rank)
     batch = fm.ObservationBatch(data["grid"], data["start"], data["direction"], data["target"], data["speed"], depth,
                                 device=device)
-    batch.reset(sync=True)          # sizes the rail axis (one host read-back), allocates every buffer
-    batch.observations()
+    batch.reset_fused(sync=True)    # sizes the rail axis (one host read-back), allocates every buffer
     Rp, T1 = batch.Rp, batch.T1
 
     def step(ev=None):
-        batch.reset(sync=False)
+        batch.build_graph(sync=False)
+        batch.compute_distances()
+        batch.shortest_paths()
+        batch.columns(shift=1)
         if ev is not None:
             ev[0].record()
-        batch.observations()
+        batch.observations_fused()
         if ev is not None:
             ev[1].record()
 
@@ -147,8 +149,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, desc), "envs_per_gpu": E, "agents": A,
                        "rails_padded": int(Rp), "depth": depth, "agents_flagged": n_err,
-                       "step": "graph build + distance BFS + shortest paths + occupancy planes + observations"},
-            "roofline": {"kernel": "observations_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
+                       "step": "graph build + distance maps + shortest paths + occupancy columns + observations (dense planes are plane 0 of each observation)"},
+            "roofline": {"kernel": "observations_columns_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": obs_ms},
             "observations_only": {"value": E * A / (obs_ms * 1e-3), "unit": "agent-observations/s",

@@ -217,12 +217,48 @@ class ObservationBatch:
                 torch.empty(shape, dtype=torch.int8, device=dev)
         if getattr(self, "agent_err", None) is None:
             self.agent_err = torch.empty((E, A), dtype=torch.int32, device=dev)
+        if getattr(self, "cols", None) is None:
+            self.cols = torch.empty((E, A, self.T1), dtype=torch.int16, device=dev)
         call("flm_bitmaps", ptr(self.path_cell), ptr(self.path_len), None, ptr(self.pos_cell), ptr(self.target_cell),
              ptr(self.tpc), ptr(self.node_id), ptr(self.cell_rail), ptr(self.edge_info), E, A, E * A, self.H, self.W,
-             self.capR, self.Rp, self.T1, self.plane_stride, self.Lcap, int(shift), ptr(out), ptr(self.agent_err),
-             self.stream.cuda_stream)
+             self.capR, self.Rp, self.T1, self.plane_stride, self.Lcap, int(shift), ptr(self.cols), ptr(out),
+             ptr(self.agent_err), self.stream.cuda_stream)
         self.maps = out
         return out
+
+    def columns(self, shift=1):
+        """Column form of the occupancy planes of the current paths: [E,A,T1] int16, rail*2 + (sign > 0) or -1."""
+        E, A, dev = self.E, self.A, self.device
+        if getattr(self, "cols", None) is None:
+            self.cols = torch.empty((E, A, self.T1), dtype=torch.int16, device=dev)
+        if getattr(self, "agent_err", None) is None:
+            self.agent_err = torch.empty((E, A), dtype=torch.int32, device=dev)
+        call("flm_columns", ptr(self.path_cell), ptr(self.path_len), None, ptr(self.pos_cell), ptr(self.target_cell),
+             ptr(self.tpc), ptr(self.node_id), ptr(self.cell_rail), ptr(self.edge_info), E, A, E * A, self.H, self.W,
+             self.capR, self.Rp, self.T1, self.Lcap, int(shift), ptr(self.cols), ptr(self.agent_err),
+             self.stream.cuda_stream)
+        return self.cols
+
+    def observations_fused(self, out=None):
+        """Observations of every agent straight from the column form; obs[:, :, 0] are the dense planes."""
+        if self.A > 255:
+            raise ValueError("heat counts are stored in 8 bits: at most 255 agents per environment")
+        if out is None:
+            shape = (self.E, self.A, 3, self.plane_stride)
+            out = self.obs if (self.obs is not None and tuple(self.obs.shape) == shape) else \
+                torch.empty(shape, dtype=torch.uint8, device=self.device)
+        call("flm_observations_columns", ptr(self.cols), self.E, self.A, self.Rp, self.T1, self.plane_stride, ptr(out),
+             self.stream.cuda_stream)
+        self.obs = out
+        return out
+
+    def reset_fused(self, sync=True):
+        """reset() + observations() without the dense intermediate planes."""
+        self.build_graph(sync=sync)
+        self.compute_distances()
+        self.shortest_paths()
+        self.columns(shift=1)
+        return self.observations_fused()
 
     def observations(self, maps=None, own=None, out=None):
         """[E,A,3,plane_stride] uint8: own plane, positive heat, negative heat (src/preprocessing.py:24-30,61-74)."""
@@ -278,10 +314,11 @@ class ObservationBatch:
         n = agent_flat.numel()
         planes = torch.empty((n, self.plane_stride), dtype=torch.int8, device=self.device)
         err = torch.empty((n,), dtype=torch.int32, device=self.device)
+        cols = torch.empty((n, self.T1), dtype=torch.int16, device=self.device)
         call("flm_bitmaps", ptr(path_cell), ptr(path_len), ptr(agent_flat), ptr(self.pos_cell), ptr(self.target_cell),
              ptr(self.tpc), ptr(self.node_id), ptr(self.cell_rail), ptr(self.edge_info), self.E, self.A, n, self.H,
-             self.W, self.capR, self.Rp, self.T1, self.plane_stride, int(Lcap), int(shift), ptr(planes), ptr(err),
-             self.stream.cuda_stream)
+             self.W, self.capR, self.Rp, self.T1, self.plane_stride, int(Lcap), int(shift), ptr(cols), ptr(planes),
+             ptr(err), self.stream.cuda_stream)
         return planes, err
 
     def observations_for(self, maps, req_agent, own_planes=None):

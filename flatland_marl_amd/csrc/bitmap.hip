@@ -13,7 +13,7 @@ __global__ __launch_bounds__(256) void bitmaps_kernel(
     const int32_t* __restrict__ pos_cell, const int32_t* __restrict__ target_cell, const int32_t* __restrict__ tpc_all,
     const int32_t* __restrict__ node_id_all, const int32_t* __restrict__ cell_rail_all,
     const int32_t* __restrict__ edge_info_all, int A, int H, int W, int capR, int Rp, int T1, int plane_stride,
-    int Lcap, int shift, int8_t* __restrict__ planes, int32_t* __restrict__ err_out) {
+    int Lcap, int shift, int8_t* __restrict__ planes, int16_t* __restrict__ cols, int32_t* __restrict__ err_out) {
   extern __shared__ __attribute__((aligned(16))) int lds[];
   int* s_cell = lds;             // [T1] predicted cell
   int* s_rail = lds + T1;        // [T1] rail in that cell or -1
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void bitmaps_kernel(
   const int32_t* node_id = node_id_all + (size_t)e * HW;
   const int32_t* cell_rail = cell_rail_all + (size_t)e * HW;
   const int32_t* edge_info = edge_info_all + (size_t)e * capR * 5;
-  int8_t* plane = planes + (size_t)gp * plane_stride;
+  int8_t* plane = planes ? planes + (size_t)gp * plane_stride : nullptr;
 
   if (tid == 0) {
     s_misc[0] = len > 0 ? len - 1 : 0;
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void bitmaps_kernel(
     s_misc[2] = 0;
   }
   // clear the plane
-  {
+  if (plane) {
     uint4 z = make_uint4(0, 0, 0, 0);
     uint4* p4 = reinterpret_cast<uint4*>(plane);
     for (int i = tid; i < plane_stride / 16; i += 256) p4[i] = z;
@@ -131,12 +131,231 @@ __global__ __launch_bounds__(256) void bitmaps_kernel(
     err_out[gp] = err;
   }
   __syncthreads();  // also orders the clearing stores before the bytes written below
-  if (s_misc[2] == 0) {
+  const bool ok = s_misc[2] == 0;
+  if (plane && ok) {
     for (int ts = tid; ts < n; ts += 256) {
       int rail = s_orail[ts];
       int t = ts + shift;
       if (rail >= 0 && rail < Rp && t < T1) plane[(size_t)rail * T1 + t] = (int8_t)s_oval[ts];
     }
+  }
+  if (cols) {
+    // column form of the same plane: per time step, rail*2 + (sign > 0), or -1 when the column is empty
+    int16_t* col = cols + (size_t)gp * T1;
+    for (int t = tid; t < T1; t += 256) {
+      int ts = t - shift;
+      int v = -1;
+      if (ok && ts >= 0 && ts < n) {
+        int rail = s_orail[ts];
+        if (rail >= 0 && rail < Rp) v = rail * 2 + (s_oval[ts] > 0 ? 1 : 0);
+      }
+      col[t] = (int16_t)v;
+    }
+  }
+}
+
+// ---- column form, one wavefront per path ---------------------------------------------------------------
+// The same plane as bitmaps_kernel, produced without a sequential pass.  Lane l owns the time steps
+// l, l+64, ...  The two order-dependent quantities of the sequential definition become bit scans over
+// wave ballots (one 64-bit mask per 64 steps):
+//   * the node through which the current rail was entered = the last earlier step that left a switch
+//     cell (highest set bit below the step in the "leaves a switch" masks), or the initial entry;
+//   * a step on a switch cell shows the rail and sign of the next step that is on a rail
+//     (lowest set bit above the step in the "on a rail" masks).
+// The first error in time order is the one reported, as in the sequential definition.
+#define FLM_COL_KT 8   // up to 512 time steps
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+  return v;
+}
+
+__global__ __launch_bounds__(256) void columns_wave_kernel(
+    const int32_t* __restrict__ path_cell, const int32_t* __restrict__ path_len, const int32_t* __restrict__ agent_flat,
+    const int32_t* __restrict__ pos_cell, const int32_t* __restrict__ target_cell, const int32_t* __restrict__ tpc_all,
+    const int32_t* __restrict__ node_id_all, const int32_t* __restrict__ cell_rail_all,
+    const int32_t* __restrict__ edge_info_all, int A, int n_paths, int H, int W, int capR, int Rp, int T1, int Lcap,
+    int shift, int16_t* __restrict__ cols, int32_t* __restrict__ err_out) {
+  extern __shared__ __attribute__((aligned(16))) int lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int gp = blockIdx.x * 4 + wave;
+  if (gp >= n_paths) return;   // wave-uniform; no workgroup barrier is used below
+  int* s_cell = lds + wave * 4 * T1;
+  int* s_rail = s_cell + T1;
+  int* s_node = s_rail + T1;
+  int* s_dir = s_node + T1;
+  const int ga = agent_flat ? agent_flat[gp] : gp;
+  const int e = ga / A;
+  const int HW = H * W;
+  const int pos = pos_cell[ga], tgt = target_cell[ga];
+  int tpc = tpc_all[ga];
+  if (tpc < 1) tpc = 1;
+  int len = path_len[gp];
+  if (len > Lcap) len = Lcap;
+  const int32_t* pcell = path_cell + (size_t)gp * Lcap;
+  const int32_t* node_id = node_id_all + (size_t)e * HW;
+  const int32_t* cell_rail = cell_rail_all + (size_t)e * HW;
+  const int32_t* edge_info = edge_info_all + (size_t)e * capR * 5;
+  const int KT = (T1 + 63) >> 6;
+
+  // the agent stops advancing at the first path element on the target cell
+  int kmin = len > 0 ? len - 1 : 0;
+  for (int k = lane; k < len; k += 64) {
+    const int c = (k == 0) ? pos : pcell[k];
+    if (c == tgt) kmin = min(kmin, k);
+  }
+  const int kstop = wave_min(kmin);
+  int nmin = T1;
+  for (int q = 0; q < KT; q++) {
+    const int ts = lane + 64 * q;
+    if (ts < T1) {
+      int k = ts / tpc;
+      if (k > kstop) k = kstop;
+      const int c = (k == 0) ? pos : pcell[k];
+      const bool inside = c >= 0 && c < HW;
+      s_cell[ts] = c;
+      s_rail[ts] = inside ? cell_rail[c] : -1;
+      s_node[ts] = inside ? node_id[c] : -1;
+      if (c == tgt) nmin = min(nmin, ts + 1);
+    }
+  }
+  const int n = wave_min(nmin);   // steps kept: cut after the first visit of the target
+  __builtin_amdgcn_wave_barrier();
+
+  // masks over the kept steps
+  unsigned long long m_rail[FLM_COL_KT], m_ev[FLM_COL_KT];
+  int key_err_ts = 0x7FFFFFFF;   // first step at which leaving a cell that is neither rail nor node fails
+#pragma unroll
+  for (int q = 0; q < FLM_COL_KT; q++) {
+    m_rail[q] = 0;
+    m_ev[q] = 0;
+    if (q < KT) {
+      const int ts = lane + 64 * q;
+      bool on_rail = false, ev = false;
+      if (ts < n) {
+        on_rail = s_rail[ts] != -1;
+        ev = !on_rail && ts + 1 < n && s_cell[ts] != s_cell[ts + 1];
+        if (ev && s_node[ts] < 0) key_err_ts = min(key_err_ts, ts);
+      }
+      m_rail[q] = __ballot(on_rail);
+      m_ev[q] = __ballot(ev);
+    }
+  }
+  // initial entry (wave-uniform)
+  int err = 0, en0 = -1, ecp0 = -1;
+  if (s_rail[0] != -1) {
+    int i = -1;   // first kept step >= 1 that is not on a rail
+#pragma unroll
+    for (int q = FLM_COL_KT - 1; q >= 0; q--)
+      if (q < KT) {
+        unsigned long long valid = (n - 64 * q >= 64) ? ~0ull : ((n - 64 * q) > 0 ? ((1ull << (n - 64 * q)) - 1) : 0ull);
+        unsigned long long holes = ~m_rail[q] & valid;
+        if (q == 0) holes &= ~1ull;
+        if (holes) i = 64 * q + __ffsll((long long)holes) - 1;
+      }
+    if (i < 0) err = FLM_AGENT_INDEX_ERROR;
+    else {
+      const int nid = s_node[i];
+      if (nid < 0) err = FLM_AGENT_KEY_ERROR;
+      else {
+        const int c0 = s_cell[i - 1], c1 = s_cell[i];
+        const int cp = (direction_to_point(c0 / W, c0 % W, c1 / W, c1 % W) + 2) & 3;
+        const int32_t* ei = edge_info + s_rail[0] * 5;
+        if (nid == ei[2] && cp == ei[3]) { en0 = ei[0]; ecp0 = ei[1]; }
+        else if (nid == ei[0] && cp == ei[1]) { en0 = ei[2]; ecp0 = ei[3]; }
+      }
+    }
+  } else {
+    const int nid = s_node[0];
+    if (nid < 0) err = FLM_AGENT_KEY_ERROR;
+    else if (n < 2) err = FLM_AGENT_INDEX_ERROR;
+    else {
+      const int c0 = s_cell[0], c1 = s_cell[1];
+      en0 = nid;
+      ecp0 = direction_to_point(c0 / W, c0 % W, c1 / W, c1 % W);
+    }
+  }
+  // sign of every step on a rail
+  int assert_err_ts = 0x7FFFFFFF;
+#pragma unroll
+  for (int q = 0; q < FLM_COL_KT; q++)
+    if (q < KT) {
+      const int ts = lane + 64 * q;
+      if (ts < n && ((m_rail[q] >> lane) & 1)) {
+        // last earlier step that left a switch cell
+        int le = -1;
+        unsigned long long below = m_ev[q] & lanemask_lt();
+        if (below) le = 64 * q + 63 - __clzll((long long)below);
+        else {
+#pragma unroll
+          for (int p = FLM_COL_KT - 1; p >= 0; p--)
+            if (p < q && le < 0 && m_ev[p]) le = 64 * p + 63 - __clzll((long long)m_ev[p]);
+        }
+        int en = en0, ecp = ecp0;
+        if (le >= 0) {
+          const int c0 = s_cell[le], c1 = s_cell[le + 1];
+          en = s_node[le];
+          ecp = direction_to_point(c0 / W, c0 % W, c1 / W, c1 % W);
+        }
+        const int32_t* ei = edge_info + s_rail[ts] * 5;
+        int dir = 0;
+        if (en == ei[2] && ecp == ei[3]) dir = 1;
+        else if (en == ei[0] && ecp == ei[1]) dir = -1;
+        if (dir == 0) assert_err_ts = min(assert_err_ts, ts);
+        s_dir[ts] = dir;
+      }
+    }
+  if (!err) {
+    const int k_ts = wave_min(key_err_ts), a_ts = wave_min(assert_err_ts);
+    if (k_ts != 0x7FFFFFFF || a_ts != 0x7FFFFFFF) err = (k_ts < a_ts) ? FLM_AGENT_KEY_ERROR : FLM_AGENT_ASSERT_ERROR;
+  }
+  if (lane == 0) err_out[gp] = err;
+  __builtin_amdgcn_wave_barrier();
+  // output: a step on a rail shows itself, a step on a switch cell the next step that is on a rail
+  int16_t* col = cols + (size_t)gp * T1;
+  for (int t = lane; t < T1; t += 64) {
+    const int ts = t - shift;
+    int v = -1;
+    if (!err && ts >= 0 && ts < n) {
+      const int q = ts >> 6, b = ts & 63;
+      int src = -1;
+      unsigned long long mq = 0;
+#pragma unroll
+      for (int p = 0; p < FLM_COL_KT; p++)
+        if (p == q) mq = m_rail[p];
+      if ((mq >> b) & 1) src = ts;
+      else {
+        unsigned long long above = (b == 63) ? 0ull : (mq & (~0ull << (b + 1)));
+        if (above) src = 64 * q + __ffsll((long long)above) - 1;
+        else {
+#pragma unroll
+          for (int p = 0; p < FLM_COL_KT; p++)
+            if (p > q && src < 0 && m_rail[p]) src = 64 * p + __ffsll((long long)m_rail[p]) - 1;
+        }
+      }
+      if (src >= 0) {
+        const int rail = s_rail[src];
+        if (rail < Rp) v = rail * 2 + (s_dir[src] > 0 ? 1 : 0);
+      }
+    }
+    col[t] = (int16_t)v;
+  }
+}
+
+// Dense plane of every path from its column form: clear with 16-byte stores, then one byte per column.
+__global__ __launch_bounds__(256) void planes_from_columns_kernel(const int16_t* __restrict__ cols, int T1,
+                                                                  int plane_stride, int8_t* __restrict__ planes) {
+  const int gp = blockIdx.x, tid = threadIdx.x;
+  int8_t* plane = planes + (size_t)gp * plane_stride;
+  const uint4 z = make_uint4(0, 0, 0, 0);
+  uint4* p4 = reinterpret_cast<uint4*>(plane);
+  for (int i = tid; i < plane_stride / 16; i += 256) p4[i] = z;
+  __syncthreads();   // orders the clearing stores of the workgroup before the bytes below
+  const int16_t* col = cols + (size_t)gp * T1;
+  for (int t = tid; t < T1; t += 256) {
+    const int c = col[t];
+    if (c >= 0) plane[(size_t)(c >> 1) * T1 + t] = (c & 1) ? (int8_t)1 : (int8_t)-1;
   }
 }
 
@@ -230,6 +449,80 @@ __global__ __launch_bounds__(1024) void observations_kernel(const int8_t* __rest
   }
 }
 
+// Observations straight from the column form (no dense input planes): a workgroup owns 1 KiB of plane
+// positions of one environment.  Every wave walks the columns of its agents once, keeps the few entries
+// that fall into the tile in registers and counts them into two packed-byte totals in LDS.  After the
+// barrier it writes, per agent, the own plane (zeros except those entries, staged through a per-wave LDS
+// tile) and total-minus-self for both signs.  The kernel only writes to HBM: 3 bytes per position and agent.
+template <int APW, int KT>
+__global__ __launch_bounds__(1024) void observations_columns_kernel(const int16_t* __restrict__ cols, int A, int T1,
+                                                                    int plane_stride, uint8_t* __restrict__ obs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned lds_u[];
+  unsigned* tot_pos = lds_u;          // [256] packed bytes
+  unsigned* tot_neg = lds_u + 256;    // [256]
+  const int nw = blockDim.x >> 6;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned char* own = reinterpret_cast<unsigned char*>(lds_u + 512) + wave * 1024;   // per-wave tile
+  const int e = blockIdx.y;
+  const int p0 = blockIdx.x * 1024;
+  for (int i = threadIdx.x; i < 512; i += blockDim.x) lds_u[i] = 0;
+  __syncthreads();
+  int hit_p[APW][KT];   // offset inside the tile, -1 = none
+  int hit_v[APW][KT];   // +1 / -1
+#pragma unroll
+  for (int i = 0; i < APW; i++) {
+    const int a = wave + i * nw;
+#pragma unroll
+    for (int k = 0; k < KT; k++) {
+      const int t = lane + 64 * k;
+      hit_p[i][k] = -1;
+      hit_v[i][k] = 0;
+      if (a < A && t < T1) {
+        const int c = cols[((size_t)e * A + a) * T1 + t];
+        if (c >= 0) {
+          const int p = (c >> 1) * T1 + t - p0;
+          if (p >= 0 && p < 1024) {
+            hit_p[i][k] = p;
+            hit_v[i][k] = (c & 1) ? 1 : -1;
+            atomicAdd(((c & 1) ? tot_pos : tot_neg) + (p >> 2), 1u << ((p & 3) * 8));
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const size_t off = (size_t)p0 + (size_t)lane * 16;
+  const bool active = off < (size_t)plane_stride;
+  const uint4 ptot = reinterpret_cast<const uint4*>(tot_pos)[lane];
+  const uint4 ntot = reinterpret_cast<const uint4*>(tot_neg)[lane];
+  const uint4 zero = make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < APW; i++) {
+    const int a = wave + i * nw;
+    if (a >= A) continue;   // wave-uniform
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < KT; k++) any |= hit_p[i][k] >= 0;
+    uint4 mine = zero;
+    if (__ballot(any)) {   // wave-uniform: this agent has entries in the tile
+      reinterpret_cast<uint4*>(own)[lane] = zero;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < KT; k++)
+        if (hit_p[i][k] >= 0) own[hit_p[i][k]] = (unsigned char)hit_v[i][k];
+      __builtin_amdgcn_wave_barrier();
+      mine = reinterpret_cast<const uint4*>(own)[lane];
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (active) {
+      uint8_t* o = obs + ((size_t)e * A + a) * 3 * plane_stride + off;
+      store16<true>(o, mine);
+      store16<true>(o + plane_stride, sub4(ptot, pos_bits4(mine)));
+      store16<true>(o + 2 * (size_t)plane_stride, sub4(ntot, neg_bits4(mine)));
+    }
+  }
+}
+
 // Observation of selected agents only: request g asks for agent req_agent[g] (= e*A + a); the plane shown
 // as its own is own_planes[g] when given, else its plane in maps.  One workgroup per (1 KiB tile, request).
 __global__ __launch_bounds__(64) void observations_req_kernel(const int8_t* __restrict__ maps,
@@ -260,22 +553,58 @@ __global__ __launch_bounds__(64) void observations_req_kernel(const int8_t* __re
 
 }  // namespace flm
 
+static int launch_columns(const int32_t* path_cell, const int32_t* path_len, const int32_t* agent_flat,
+                          const int32_t* pos_cell, const int32_t* target_cell, const int32_t* tpc,
+                          const int32_t* node_id, const int32_t* cell_rail, const int32_t* edge_info, int A, int n_paths,
+                          int H, int W, int capR, int Rp, int T1, int Lcap, int shift, int16_t* cols, int32_t* err,
+                          hipStream_t stream) {
+  if (T1 <= 64 * FLM_COL_KT) {
+    size_t lds = sizeof(int) * 16 * (size_t)T1;
+    hipLaunchKernelGGL(flm::columns_wave_kernel, dim3((n_paths + 3) / 4), dim3(256), lds, stream, path_cell, path_len,
+                       agent_flat, pos_cell, target_cell, tpc, node_id, cell_rail, edge_info, A, n_paths, H, W, capR, Rp, T1,
+                       Lcap, shift, cols, err);
+  } else {   // longer horizons: the sequential formulation, one workgroup per path
+    size_t lds = sizeof(int) * (5 * (size_t)T1 + 4);
+    hipLaunchKernelGGL(flm::bitmaps_kernel, dim3(n_paths), dim3(256), lds, stream, path_cell, path_len, agent_flat, pos_cell,
+                       target_cell, tpc, node_id, cell_rail, edge_info, A, H, W, capR, Rp, T1, 0, Lcap, shift,
+                       (int8_t*)nullptr, cols, err);
+  }
+  FLM_CHECK_LAUNCH();
+  return FLM_OK;
+}
+
+extern "C" int flm_columns(const int32_t* path_cell, const int32_t* path_len, const int32_t* agent_flat,
+                           const int32_t* pos_cell, const int32_t* target_cell, const int32_t* tpc,
+                           const int32_t* node_id, const int32_t* cell_rail, const int32_t* edge_info, int E, int A,
+                           int n_paths, int H, int W, int capR, int Rp, int T1, int Lcap, int shift, int16_t* cols,
+                           int32_t* err, void* stream) {
+  if (!path_cell || !path_len || !pos_cell || !target_cell || !tpc || !node_id || !cell_rail || !edge_info || !cols || !err)
+    return FLM_E_ARG;
+  if (E <= 0 || A <= 0 || n_paths <= 0 || H <= 0 || W <= 0 || capR <= 0 || Rp <= 0 || Rp > 16383 || T1 <= 1 ||
+      Lcap <= 0 || shift < 0 || T1 > 8000)
+    return FLM_E_ARG;
+  if (!agent_flat && n_paths != E * A) return FLM_E_ARG;
+  return launch_columns(path_cell, path_len, agent_flat, pos_cell, target_cell, tpc, node_id, cell_rail, edge_info, A,
+                        n_paths, H, W, capR, Rp, T1, Lcap, shift, cols, err, (hipStream_t)stream);
+}
+
 extern "C" int flm_bitmaps(const int32_t* path_cell, const int32_t* path_len, const int32_t* agent_flat,
                            const int32_t* pos_cell, const int32_t* target_cell, const int32_t* tpc,
                            const int32_t* node_id, const int32_t* cell_rail, const int32_t* edge_info, int E, int A,
                            int n_paths, int H, int W, int capR, int Rp, int T1, int plane_stride, int Lcap, int shift,
-                           int8_t* planes, int32_t* err, void* stream) {
+                           int16_t* cols_ws, int8_t* planes, int32_t* err, void* stream) {
   if (!path_cell || !path_len || !pos_cell || !target_cell || !tpc || !node_id || !cell_rail || !edge_info || !planes ||
-      !err)
+      !err || !cols_ws)
     return FLM_E_ARG;
-  if (E <= 0 || A <= 0 || n_paths <= 0 || H <= 0 || W <= 0 || capR <= 0 || Rp <= 0 || T1 <= 1 || Lcap <= 0 ||
-      shift < 0 || plane_stride % 16 != 0 || (long long)plane_stride < (long long)Rp * T1 || T1 > 8000)
+  if (E <= 0 || A <= 0 || n_paths <= 0 || H <= 0 || W <= 0 || capR <= 0 || Rp <= 0 || Rp > 16383 || T1 <= 1 ||
+      Lcap <= 0 || shift < 0 || plane_stride % 16 != 0 || (long long)plane_stride < (long long)Rp * T1 || T1 > 8000)
     return FLM_E_ARG;
   if (!agent_flat && n_paths != E * A) return FLM_E_ARG;
-  size_t lds = sizeof(int) * (5 * (size_t)T1 + 4);
-  hipLaunchKernelGGL(flm::bitmaps_kernel, dim3(n_paths), dim3(256), lds, (hipStream_t)stream, path_cell, path_len,
-                     agent_flat, pos_cell, target_cell, tpc, node_id, cell_rail, edge_info, A, H, W, capR, Rp, T1,
-                     plane_stride, Lcap, shift, planes, err);
+  int rc = launch_columns(path_cell, path_len, agent_flat, pos_cell, target_cell, tpc, node_id, cell_rail, edge_info, A,
+                          n_paths, H, W, capR, Rp, T1, Lcap, shift, cols_ws, err, (hipStream_t)stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(flm::planes_from_columns_kernel, dim3(n_paths), dim3(256), 0, (hipStream_t)stream, cols_ws, T1,
+                     plane_stride, planes);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }
@@ -334,6 +663,45 @@ extern "C" int flm_observations(const int8_t* maps, const int8_t* own, int E, in
                             : launch_obs_apw<2, false>(maps, own, E, A, plane_stride, obs, nw, stream);
   return nt ? launch_obs_apw<4, true>(maps, own, E, A, plane_stride, obs, nw, stream)
             : launch_obs_apw<4, false>(maps, own, E, A, plane_stride, obs, nw, stream);
+}
+
+template <int APW, int KT>
+static int launch_obs_cols(const int16_t* cols, int E, int A, int T1, int plane_stride, uint8_t* obs, int nw,
+                           hipStream_t stream) {
+  dim3 grid((plane_stride + 1023) / 1024, E);
+  size_t lds = 2048 + 1024 * (size_t)nw;
+  hipLaunchKernelGGL((flm::observations_columns_kernel<APW, KT>), grid, dim3(nw * 64), lds, stream, cols, A, T1,
+                     plane_stride, obs);
+  FLM_CHECK_LAUNCH();
+  return FLM_OK;
+}
+
+template <int KT>
+static int launch_obs_cols_apw(const int16_t* cols, int E, int A, int T1, int plane_stride, uint8_t* obs, int nw,
+                               hipStream_t stream) {
+  int apw = (A + nw - 1) / nw;
+  if (apw <= 1) return launch_obs_cols<1, KT>(cols, E, A, T1, plane_stride, obs, nw, stream);
+  if (apw <= 2) return launch_obs_cols<2, KT>(cols, E, A, T1, plane_stride, obs, nw, stream);
+  if (apw <= 4) return launch_obs_cols<4, KT>(cols, E, A, T1, plane_stride, obs, nw, stream);
+  if (apw <= 8) return launch_obs_cols<8, KT>(cols, E, A, T1, plane_stride, obs, nw, stream);
+  if (apw <= 16) return launch_obs_cols<16, KT>(cols, E, A, T1, plane_stride, obs, nw, stream);
+  return FLM_E_ARG;
+}
+
+extern "C" int flm_observations_columns(const int16_t* cols, int E, int A, int Rp, int T1, int plane_stride,
+                                        uint8_t* obs, void* stream_) {
+  if (!cols || !obs) return FLM_E_ARG;
+  if (E <= 0 || E > 65535 || A <= 0 || A > 255 || Rp <= 0 || T1 <= 1 || T1 > 512 || plane_stride % 16 != 0 ||
+      (long long)plane_stride < (long long)Rp * T1)
+    return FLM_E_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  int nw = A < 16 ? A : 16;
+  int kt = (T1 + 63) / 64;
+  if (kt <= 1) return launch_obs_cols_apw<1>(cols, E, A, T1, plane_stride, obs, nw, stream);
+  if (kt <= 2) return launch_obs_cols_apw<2>(cols, E, A, T1, plane_stride, obs, nw, stream);
+  if (kt <= 3) return launch_obs_cols_apw<3>(cols, E, A, T1, plane_stride, obs, nw, stream);
+  if (kt <= 5) return launch_obs_cols_apw<5>(cols, E, A, T1, plane_stride, obs, nw, stream);
+  return launch_obs_cols_apw<8>(cols, E, A, T1, plane_stride, obs, nw, stream);
 }
 
 extern "C" int flm_observations_req(const int8_t* maps, const int32_t* req_agent, const int8_t* own_planes, int n_req,

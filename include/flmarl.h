@@ -128,12 +128,13 @@ int flm_shortest_paths(const uint16_t* grid, const int32_t* cell_idx, const uint
  *   n_paths paths in all: path_cell [n_paths,Lcap], path_len [n_paths]; agent_flat [n_paths] int32 gives
  *   the agent (e*A + a) each path belongs to (NULL = identity, n_paths == E*A); pos_cell [E,A] the agent's
  *   virtual position (src/predictions.py:89-94); tpc [E,A] time steps per cell;
- *   planes [n_paths,plane_stride] int8 out; err [n_paths] int32 out. */
+ *   planes [n_paths,plane_stride] int8 out; err [n_paths] int32 out; cols_ws [n_paths,T1] int16 is a
+ *   workspace that receives the column form (see flm_columns). */
 int flm_bitmaps(const int32_t* path_cell, const int32_t* path_len, const int32_t* agent_flat,
                 const int32_t* pos_cell, const int32_t* target_cell, const int32_t* tpc,
                 const int32_t* node_id, const int32_t* cell_rail, const int32_t* edge_info, int E, int A,
                 int n_paths, int H, int W, int capR, int Rp, int T1, int plane_stride, int Lcap, int shift,
-                int8_t* planes, int32_t* err, void* stream);
+                int16_t* cols_ws, int8_t* planes, int32_t* err, void* stream);
 
 /* Observation of every agent: its own plane and the two heat planes "sum over the other agents" of the
  * positive and of the negative entries.
@@ -144,6 +145,21 @@ int flm_bitmaps(const int32_t* path_cell, const int32_t* path_len, const int32_t
  * A <= 255. */
 int flm_observations(const int8_t* maps, const int8_t* own, int E, int A, int plane_stride, uint8_t* obs,
                      void* stream);
+
+/* The fused form of flm_bitmaps + flm_observations, which never materialises the dense input planes:
+ *   flm_columns              same inputs as flm_bitmaps; cols [n_paths,T1] int16 out: per time step
+ *                            rail*2 + (sign > 0), -1 where the column is empty (a plane has at most one
+ *                            entry per column, src/rail_observations.py:397-401); err as flm_bitmaps;
+ *   flm_observations_columns cols [E,A,T1] -> obs [E,A,3,plane_stride] uint8, identical to what
+ *                            flm_observations writes for the planes those columns describe.  obs[e,a,0]
+ *                            is the agent's dense plane (stride 3*plane_stride between agents).
+ * T1 <= 512, A <= 255, Rp <= 16383. */
+int flm_columns(const int32_t* path_cell, const int32_t* path_len, const int32_t* agent_flat,
+                const int32_t* pos_cell, const int32_t* target_cell, const int32_t* tpc, const int32_t* node_id,
+                const int32_t* cell_rail, const int32_t* edge_info, int E, int A, int n_paths, int H, int W, int capR,
+                int Rp, int T1, int Lcap, int shift, int16_t* cols, int32_t* err, void* stream);
+int flm_observations_columns(const int16_t* cols, int E, int A, int Rp, int T1, int plane_stride, uint8_t* obs,
+                             void* stream);
 
 /* The same observation for selected agents only (rollout: the agents that consult the network this step).
  * Replaces one ObsPreprocessor.get_obs call per request, src/preprocessing.py:61-74.

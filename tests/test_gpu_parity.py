@@ -140,3 +140,35 @@ def test_batched_envs_match_single():
         for a in (0, 17, 79):
             want = orc.get_obs(maps[perms[e]], a, maps[perms[e]][a], 100).reshape(3, 100, depth + 1)
             assert np.array_equal(obs[a], want)
+
+
+@pytest.mark.parametrize("name,depth", [("Test_0_Level_0", 150), ("Test_3_Level_0", 150), ("Test_6_Level_0", 150),
+                                        ("Test_8_Level_1", 150), ("Test_9_Level_1", 300), ("Test_1_Level_1", 40)])
+def test_fused_observations_equal_unfused(name, depth):
+    """Column form + fused kernel write exactly the bytes of planes + observation kernel (errors included)."""
+    import torch
+    fx = load_env(name)
+    b = _batch(fx, depth)
+    b.reset()
+    want = b.observations().clone()
+    err = b.agent_err.clone()
+    want_maps = b.maps.clone()
+    b.obs = None
+    got = b.reset_fused()
+    assert torch.equal(b.agent_err, err)
+    assert torch.equal(got, want)
+    # plane 0 of the observation is the dense occupancy plane
+    assert torch.equal(got[:, :, 0].contiguous().view(torch.int8), want_maps)
+
+
+def test_long_horizon_uses_sequential_formulation():
+    """depth 600 (> 512 time steps) takes the one-workgroup-per-path kernel; same planes as the checker."""
+    from oracle import oracle as orc
+    depth = 600
+    fx = load_env("Test_1_Level_0")
+    b = _batch(fx, depth)
+    b.reset()
+    env = orc.OracleEnv(fx, depth)
+    maps, _, errs = env.get_many()
+    assert [ERR.get(x, 0) for x in errs] == list(b.agent_err[0].cpu().numpy())
+    assert np.array_equal(b.maps_numpy(0), maps)

@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--envs", type=int, default=0)
     ap.add_argument("--obs-variants", default="0")
     ap.add_argument("--bfs-variants", default="0")
-    ap.add_argument("--stages", default="graph,bfs,paths,bitmaps,obs")
+    ap.add_argument("--stages", default="graph,bfs,paths,bitmaps,obs,fused")
     args = ap.parse_args()
     names, E, A, depth, desc = bench.WORKLOADS[args.workload]
     E = args.envs or E
@@ -72,6 +72,13 @@ def main():
         out["bitmaps_ms"] = timed(lambda: b.bitmaps(shift=1))
         out["bitmaps_equal"] = bool(torch.equal(b.maps, ref_maps))
         out["bitmaps_GBs"] = E * A * b.plane_stride / out["bitmaps_ms"][0] / 1e6
+    if "fused" in stages:
+        out["columns_ms"] = timed(lambda: b.columns(shift=1))
+        b.obs.zero_()
+        t = timed(b.observations_fused)
+        out["obs_fused"] = dict(ms=t, GBs_alg=4.0 * b.Rp * b.T1 * E * A / t[0] / 1e6,
+                                GBs_written=3.0 * b.plane_stride * E * A / t[0] / 1e6,
+                                ok=int(b.obs.view(torch.int64).sum().item()) == ref_obs_sum)
     if "obs" in stages:
         alg = 4.0 * b.Rp * b.T1 * E * A
         for v in [int(x) for x in args.obs_variants.split(",")]:
