@@ -71,6 +71,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=0, help="environments per GPU (default: the workload's)")
+    ap.add_argument("--chunks", type=int, default=1, help="split the batch into this many sub-batches")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the sub-batches are spread over")
+    ap.add_argument("--obs-lds-pad", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--obs-serial", type=int, default=1,
+                    help="1: observation kernels run one after the other on the main stream after the other stages")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -89,25 +94,67 @@ def main():
     if args.envs:
         E = args.envs
     data = make_batch(load_fixtures(names), E, A, seed=1000003 * rank)
-    batch = fm.ObservationBatch(data["grid"], data["start"], data["direction"], data["target"], data["speed"], depth,
-                                device=device)
-    batch.reset_fused(sync=True)    # sizes the rail axis (one host read-back), allocates every buffer
-    Rp, T1 = batch.Rp, batch.T1
+    # The batch is processed as `chunks` sub-batches spread over `streams` HIP streams, so that the
+    # latency-bound kernels of one sub-batch (graph, distances, paths) overlap the bandwidth-bound
+    # observation kernel of another.
+    if args.obs_lds_pad:
+        from flatland_marl_amd import _lib
+        _lib.call("flm_dev_set_option", 3, args.obs_lds_pad)
+    n_chunks = max(1, min(args.chunks, E))
+    streams = [torch.cuda.Stream(device=device) for _ in range(max(1, args.streams))] if args.streams > 1 or n_chunks > 1 \
+        else [torch.cuda.current_stream(device)]
+    main_stream = torch.cuda.current_stream(device)
+    batches = []
+    for ci in range(n_chunks):
+        lo, hi = parallel.shard_range(E, ci, n_chunks)
+        st = streams[ci % len(streams)]
+        with torch.cuda.stream(st):
+            b = fm.ObservationBatch(data["grid"][lo:hi], data["start"][lo:hi], data["direction"][lo:hi],
+                                    data["target"][lo:hi], data["speed"][lo:hi], depth, device=device, stream=st)
+            b.build_graph(sync=True)
+        batches.append(b)
+    Rp = max(b.Rp for b in batches)          # one rail padding for the whole batch
+    for b in batches:
+        b.max_rails = Rp
+        b.Rp = Rp
+        b.plane_stride = (Rp * b.T1 + 15) // 16 * 16
+        with torch.cuda.stream(b.stream):
+            b.reset_fused(sync=True)         # sizes the rail axis (one host read-back), allocates every buffer
+    torch.cuda.synchronize()
+    batch = batches[0]
+    T1 = batch.T1
 
     def step(ev=None):
-        batch.build_graph(sync=False)
-        batch.compute_distances()
-        batch.shortest_paths()
-        batch.columns(shift=1)
-        if ev is not None:
-            ev[0].record()
-        batch.observations_fused()
-        if ev is not None:
-            ev[1].record()
+        for st in streams:
+            st.wait_stream(main_stream)
+        for ci, b in enumerate(batches):
+            with torch.cuda.stream(b.stream):
+                b.build_graph(sync=False)
+                b.compute_distances()
+                b.shortest_paths()
+                b.columns(shift=1)
+                if not args.obs_serial:
+                    if ev is not None:
+                        ev[ci][0].record(b.stream)
+                    b.observations_fused()
+                    if ev is not None:
+                        ev[ci][1].record(b.stream)
+        for st in streams:
+            main_stream.wait_stream(st)
+        if args.obs_serial:
+            for ci, b in enumerate(batches):
+                if ev is not None:
+                    ev[ci][0].record(main_stream)
+                keep, b.stream = b.stream, main_stream
+                b.observations_fused()
+                b.stream = keep
+                if ev is not None:
+                    ev[ci][1].record(main_stream)
 
     for _ in range(args.warmup):
         step()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    events = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in batches]
+              for _ in range(args.steps)]
 
     def barrier():
         if world > 1:
@@ -122,18 +169,23 @@ def main():
     dt = time.perf_counter() - t0
     barrier()
     dt = parallel.max_over_ranks(dt, device)
-    batch.check_graph()
-    n_err = int((batch.agent_err != 0).sum().item())
-    obs_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    for b in batches:
+        b.check_graph()
+    n_err = int(sum((b.agent_err != 0).sum().item() for b in batches))
+    # the observation kernel is launched once per sub-batch: average duration of one launch
+    obs_ms = float(np.mean([a.elapsed_time(b) for per_step in events for a, b in per_step]))
+    E_launch = batches[0].E
 
     if rank == 0:
         total_obs = E * A * world * args.steps
-        alg_bytes = 4.0 * Rp * T1 * E * A          # per launch of the observation kernel
+        alg_bytes = 4.0 * Rp * T1 * E_launch * A   # per launch of the observation kernel
         achieved = alg_bytes / (obs_ms * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "obs_kernel_traffic_%s.json" % args.workload)
         if os.path.exists(tfile):
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            if traffic is not None:
+                traffic = traffic * E_launch / 4096.0   # the counters were collected on a 4096-environment launch
         out = {
             "metric": "agent-observations/sec (bitmap+heatmaps)",
             "value": total_obs / dt,
@@ -148,12 +200,12 @@ def main():
             "dtype": "i8",
             "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, desc), "envs_per_gpu": E, "agents": A,
-                       "rails_padded": int(Rp), "depth": depth, "agents_flagged": n_err,
+                       "rails_padded": int(Rp), "depth": depth, "agents_flagged": n_err, "sub_batches": n_chunks, "streams": len(streams),
                        "step": "graph build + distance maps + shortest paths + occupancy columns + observations (dense planes are plane 0 of each observation)"},
             "roofline": {"kernel": "observations_columns_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": obs_ms},
-            "observations_only": {"value": E * A / (obs_ms * 1e-3), "unit": "agent-observations/s",
+            "observations_only": {"value": E_launch * A / (obs_ms * 1e-3), "unit": "agent-observations/s",
                                   "note": "heat/observation sweep alone, one GPU"},
         }
         if world == 1 and not args.no_cpu_baseline:

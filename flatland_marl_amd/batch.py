@@ -34,7 +34,7 @@ def _dev_i32(x, device):
 
 class ObservationBatch:
     def __init__(self, grid, start_rc, direction, target_rc, speed, depth, max_rails=None, status=None,
-                 device="cuda:0"):
+                 device="cuda:0", stream=None):
         if not torch.cuda.is_available():
             raise _lib.FlmError("no GPU visible: the observation path has no CPU implementation")
         _lib.load()
@@ -64,7 +64,8 @@ class ObservationBatch:
         self.R = None
         self.maps = None
         self.obs = None
-        self.stream = torch.cuda.current_stream(self.device)
+        # every kernel of this batch is enqueued on one stream (default: the stream current at construction)
+        self.stream = torch.cuda.current_stream(self.device) if stream is None else stream
 
     # ------------------------------------------------------------------ graph
     def _alloc_graph(self, capN, capR, capC):

@@ -1,6 +1,8 @@
 // Path -> rail-occupancy plane, and the per-agent observation (own plane + two heat planes).
 #include "flm_common.h"
 
+int g_flm_dev_opt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // benchmark tuning hooks, see flm_dev_set_option
+
 namespace flm {
 
 // One 256-thread workgroup per (environment, path).  All threads clear the plane with 16-byte stores
@@ -609,7 +611,7 @@ extern "C" int flm_bitmaps(const int32_t* path_cell, const int32_t* path_len, co
   return FLM_OK;
 }
 
-int g_flm_dev_opt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
 // Tuning hook for benchmarks (not part of the stable interface): key 0 = observation kernel variant.
 extern "C" int flm_dev_set_option(int key, int value) {
   if (key < 0 || key >= 8) return FLM_E_ARG;
@@ -669,7 +671,10 @@ template <int APW, int KT>
 static int launch_obs_cols(const int16_t* cols, int E, int A, int T1, int plane_stride, uint8_t* obs, int nw,
                            hipStream_t stream) {
   dim3 grid((plane_stride + 1023) / 1024, E);
-  size_t lds = 2048 + 1024 * (size_t)nw;
+  size_t lds = 2048 + 1024 * (size_t)nw + (size_t)g_flm_dev_opt[3] * 1024;   // dev option 3: LDS padding in KiB (limits workgroups per CU)
+  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(flm::observations_columns_kernel<APW, KT>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return FLM_E_LAUNCH;
   hipLaunchKernelGGL((flm::observations_columns_kernel<APW, KT>), grid, dim3(nw * 64), lds, stream, cols, A, T1,
                      plane_stride, obs);
   FLM_CHECK_LAUNCH();

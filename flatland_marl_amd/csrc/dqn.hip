@@ -51,6 +51,7 @@ struct GemmArgs {
   long a_zs, b_zs, c_zs;
   int relu, accumulate;
   int H3;              // EPI_CONV: rows are (b,h) with h < H3; C index = b*N*H3 + n*H3 + h
+  int ksplit;          // > 0: blockIdx.z selects the K range [z*ksplit, min(K, (z+1)*ksplit)), C += z*c_zs
 };
 
 #define GBM 128
@@ -66,9 +67,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
-  const float* A = g.A + (long)blockIdx.z * g.a_zs;
-  const float* B = g.B + (long)blockIdx.z * g.b_zs;
+  const float* A = g.A + (g.ksplit ? 0 : (long)blockIdx.z * g.a_zs);
+  const float* B = g.B + (g.ksplit ? 0 : (long)blockIdx.z * g.b_zs);
   float* C = g.C + (long)blockIdx.z * g.c_zs;
+  const int k_begin = g.ksplit ? blockIdx.z * g.ksplit : 0;
+  const int k_end = g.ksplit ? min(g.K, k_begin + g.ksplit) : g.K;
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; i++)
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  for (int k0 = 0; k0 < g.K; k0 += GBK) {
+  for (int k0 = k_begin; k0 < k_end; k0 += GBK) {
     // ---- stage A tile [GBK][GBM]
     if (A_KC) {
 #pragma unroll
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
           const float* p = A + (long)gm * g.lda + gk;
 #pragma unroll
           for (int i = 0; i < 4; i++)
-            if (gk + i < g.K) v[i] = p[i];
+            if (gk + i < k_end) v[i] = p[i];
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) As[k4 + i][m] = v[i];
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         const int k = (tid >> 5) + rep * 8, m4 = (tid & 31) * 4;
         const int gk = k0 + k, gm = m0 + m4;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (gk < g.K) {
+        if (gk < k_end) {
           const float* p = A + (long)gk * g.lda + gm;
 #pragma unroll
           for (int i = 0; i < 4; i++)
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
           const float* p = B + (long)gn * g.ldb + gk;
 #pragma unroll
           for (int i = 0; i < 4; i++)
-            if (gk + i < g.K) v[i] = p[i];
+            if (gk + i < k_end) v[i] = p[i];
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) Bs[k4 + i][n] = v[i];
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         const int k = (tid >> 5) + rep * 8, n4 = (tid & 31) * 4;
         const int gk = k0 + k, gn = n0 + n4;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (gk < g.K) {
+        if (gk < k_end) {
           const float* p = B + (long)gk * g.ldb + gn;
 #pragma unroll
           for (int i = 0; i < 4; i++)
@@ -198,6 +201,18 @@ __global__ void reduce_partials_kernel(const float* __restrict__ part, int nz, l
   float s = 0.f;
   for (int z = 0; z < nz; z++) s += part[(long)z * n_elem + i];
   out[i] = s;
+}
+
+// out[m*ldo + n] = relu(bias[n] + sum over z of part[z][m][n])  (split-K reduction with the layer's epilogue)
+__global__ void reduce_bias_relu_kernel(const float* __restrict__ part, int nz, int M, int N, const float* __restrict__ bias,
+                                        float* __restrict__ out, long ldo) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)M * N) return;
+  const int m = (int)(i / N), n = (int)(i - (long)m * N);
+  float s = 0.f;
+  for (int z = 0; z < nz; z++) s += part[(long)z * M * N + i];
+  s += bias[n];
+  out[(long)m * ldo + n] = s > 0.f ? s : 0.f;
 }
 
 // column sums: out[n] = sum_m X[m*ld + n], one workgroup per 64 columns, fixed summation order
@@ -419,16 +434,20 @@ __global__ void obs_to_f32_kernel(const uint8_t* __restrict__ obs, int n, int Rp
 
 }  // namespace flm
 
+#define FLM_FC1_SPLITK 8   // K slices of the first dense layer at large batch
+
 using flm::DqnLayout;
 using flm::GemmArgs;
 
 extern "C" long flm_dqn_param_count(int H3, int T1) { return DqnLayout(H3, T1).total; }
 
 // workspace floats needed by flm_dqn_forward for a batch of B samples
-extern "C" long flm_dqn_forward_workspace(int B, int H3) { return (long)B * 64 * H3 + (long)B * 1024; }
+extern "C" long flm_dqn_forward_workspace(int B, int H3) {
+  return (long)B * 64 * H3 + (long)B * 1024 + (long)FLM_FC1_SPLITK * B * 512;
+}
 
-static int dqn_forward_impl(const float* params, const float* x, int B, int H3, int T1, float* x1, float* hid, float* q,
-                            hipStream_t stream) {
+static int dqn_forward_impl(const float* params, const float* x, int B, int H3, int T1, float* x1, float* hid, float* part,
+                            float* q, hipStream_t stream) {
   DqnLayout L(H3, T1);
   GemmArgs g{};
   // conv as GEMM: rows (b,h), K = T1, 64 filters; stored as [b][c][h] with ReLU
@@ -444,12 +463,19 @@ static int dqn_forward_impl(const float* params, const float* x, int B, int H3, 
                        L.K1, hid + 512, 1024, 512);
     if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   } else {
+    // K = 64*H3 is long and M x N small: split K over workgroups, then reduce with bias + ReLU
+    const int nz = FLM_FC1_SPLITK;
+    const int ks = (int)(((L.K1 + nz - 1) / nz + GBK - 1) / GBK * GBK);
     for (int s = 0; s < 2; s++) {
       g = GemmArgs{};
-      g.A = x1; g.B = params + (s ? L.v1_w : L.a1_w); g.C = hid + s * 512; g.bias = params + (s ? L.v1_b : L.a1_b);
-      g.M = B; g.N = 512; g.K = (int)L.K1; g.lda = L.K1; g.ldb = L.K1; g.ldc = 1024; g.relu = 1;
-      rc = flm::launch_gemm<true, true, flm::EPI_PLAIN>(g, 1, stream);
+      g.A = x1; g.B = params + (s ? L.v1_w : L.a1_w); g.C = part;
+      g.M = B; g.N = 512; g.K = (int)L.K1; g.lda = L.K1; g.ldb = L.K1; g.ldc = 512;
+      g.c_zs = (long)B * 512; g.ksplit = ks;
+      rc = flm::launch_gemm<true, true, flm::EPI_PLAIN>(g, nz, stream);
       if (rc) return rc;
+      const long ne = (long)B * 512;
+      hipLaunchKernelGGL(flm::reduce_bias_relu_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream, part, nz, B,
+                         512, params + (s ? L.v1_b : L.a1_b), hid + s * 512, 1024L);
     }
   }
   hipLaunchKernelGGL(flm::head_forward_kernel, dim3(B), dim3(64), 0, stream, hid, params + L.a2_w, params + L.a2_b,
@@ -463,7 +489,8 @@ extern "C" int flm_dqn_forward(const float* params, const float* x, int B, int H
   if (!params || !x || !workspace || !q || B <= 0 || H3 <= 0 || T1 <= 0) return FLM_E_ARG;
   float* x1 = workspace;
   float* hid = workspace + (long)B * 64 * H3;
-  return dqn_forward_impl(params, x, B, H3, T1, x1, hid, q, (hipStream_t)stream);
+  float* part = hid + (long)B * 1024;
+  return dqn_forward_impl(params, x, B, H3, T1, x1, hid, part, q, (hipStream_t)stream);
 }
 
 extern "C" int flm_obs_to_f32(const uint8_t* obs, int n, int Rp, int T1, int plane_stride, float* out, void* stream) {
@@ -481,6 +508,7 @@ extern "C" long flm_dqn_learn_workspace(int B, int H3, int T1) {
          + (long)B * 1024                                     // dhid
          + (long)B * 64 * H3                                  // dx1
          + (long)B * 64 * T1                                  // per-sample conv weight partials
+         + (long)FLM_FC1_SPLITK * B * 512                     // split-K partials of the first dense layer
          + 16L * B + 64;                                      // q's, dq, dadv, dval, squared errors, loss
 }
 
@@ -500,13 +528,14 @@ extern "C" int flm_dqn_learn_grads(const float* local, const float* target, cons
   float* dhid = hidt + n_hid;
   float* dx1 = dhid + n_hid;
   float* cpart = dx1 + n_x1;
-  float* q = cpart + (long)B * 64 * T1;
+  float* part = cpart + (long)B * 64 * T1;
+  float* q = part + (long)FLM_FC1_SPLITK * B * 512;
   float* qn = q + 2 * B; float* qt = qn + 2 * B; float* dq = qt + 2 * B;
   float* dadv = dq + 2 * B; float* dval = dadv + 2 * B; float* sq = dval + B;
   int rc;
-  if ((rc = dqn_forward_impl(local, s, B, H3, T1, x1, hid, q, stream))) return rc;
-  if ((rc = dqn_forward_impl(local, s_next, B, H3, T1, x1n, hidn, qn, stream))) return rc;
-  if ((rc = dqn_forward_impl(target, s_next, B, H3, T1, x1t, hidt, qt, stream))) return rc;
+  if ((rc = dqn_forward_impl(local, s, B, H3, T1, x1, hid, part, q, stream))) return rc;
+  if ((rc = dqn_forward_impl(local, s_next, B, H3, T1, x1n, hidn, part, qn, stream))) return rc;
+  if ((rc = dqn_forward_impl(target, s_next, B, H3, T1, x1t, hidt, part, qt, stream))) return rc;
   hipLaunchKernelGGL(flm::td_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, q, qn, qt, action, reward, done, gamma,
                      B, dq, sq);
   hipLaunchKernelGGL(flm::mean_kernel, dim3(1), dim3(64), 0, stream, sq, B, loss_out);
