@@ -60,6 +60,54 @@ struct GemmArgs {
 #define APAD 2   // k-contiguous sources are transposed on the way into LDS; this pad spreads the 4 k-groups over banks
 #define BPAD 4
 
+// Global -> register fetch of one operand tile slice owned by a thread (2 x 4 floats), and its placement in LDS.
+// KC: the source is k-contiguous (thread reads 4 consecutive k of one row, stored transposed);
+// otherwise the source is m/n-contiguous (thread reads 4 consecutive rows of one k).
+template <bool KC>
+__device__ __forceinline__ void fetch_tile(const float* __restrict__ P, long ld, int r0, int rmax, int k0, int kmax, bool vec,
+                                           int tid, float (&v)[2][4]) {
+#pragma unroll
+  for (int rep = 0; rep < 2; rep++) {
+    if (KC) {
+      const int r = r0 + (tid >> 2) + rep * 64, k = k0 + (tid & 3) * 4;
+      const float* p = P + (long)r * ld + k;
+      if (vec && r < rmax && k + 3 < kmax) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[rep][0] = t.x; v[rep][1] = t.y; v[rep][2] = t.z; v[rep][3] = t.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[rep][i] = (r < rmax && k + i < kmax) ? p[i] : 0.f;
+      }
+    } else {
+      const int k = k0 + (tid >> 5) + rep * 8, r = r0 + (tid & 31) * 4;
+      const float* p = P + (long)k * ld + r;
+      if (vec && k < kmax && r + 3 < rmax) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[rep][0] = t.x; v[rep][1] = t.y; v[rep][2] = t.z; v[rep][3] = t.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[rep][i] = (k < kmax && r + i < rmax) ? p[i] : 0.f;
+      }
+    }
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void place_tile(float (*S)[GBM + BPAD + APAD], int tid, const float (&v)[2][4]) {
+#pragma unroll
+  for (int rep = 0; rep < 2; rep++) {
+    if (KC) {
+      const int r = (tid >> 2) + rep * 64, k4 = (tid & 3) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; i++) S[k4 + i][r] = v[rep][i];
+    } else {
+      const int k = (tid >> 5) + rep * 8, r4 = (tid & 31) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; i++) S[k][r4 + i] = v[rep][i];
+    }
+  }
+}
+
 template <bool A_KC, bool B_KC, int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float As[GBK][GBM + BPAD + APAD];
@@ -72,6 +120,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   float* C = g.C + (long)blockIdx.z * g.c_zs;
   const int k_begin = g.ksplit ? blockIdx.z * g.ksplit : 0;
   const int k_end = g.ksplit ? min(g.K, k_begin + g.ksplit) : g.K;
+  // 16-byte fetches need the rows 16-byte aligned
+  const bool a_vec = (g.lda & 3) == 0 && (reinterpret_cast<size_t>(A) & 15) == 0;
+  const bool b_vec = (g.ldb & 3) == 0 && (reinterpret_cast<size_t>(B) & 15) == 0;
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; i++)
@@ -80,72 +131,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
+  // software pipeline: the next K slice is fetched into registers while the matrix cores work on the one in LDS
+  float ra[2][4], rb[2][4];
+  fetch_tile<A_KC>(A, g.lda, m0, g.M, k_begin, k_end, a_vec, tid, ra);
+  fetch_tile<B_KC>(B, g.ldb, n0, g.N, k_begin, k_end, b_vec, tid, rb);
   for (int k0 = k_begin; k0 < k_end; k0 += GBK) {
-    // ---- stage A tile [GBK][GBM]
-    if (A_KC) {
-#pragma unroll
-      for (int rep = 0; rep < 2; rep++) {
-        const int m = (tid >> 2) + rep * 64, k4 = (tid & 3) * 4;
-        const int gm = m0 + m, gk = k0 + k4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (gm < g.M) {
-          const float* p = A + (long)gm * g.lda + gk;
-#pragma unroll
-          for (int i = 0; i < 4; i++)
-            if (gk + i < k_end) v[i] = p[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) As[k4 + i][m] = v[i];
-      }
-    } else {
-#pragma unroll
-      for (int rep = 0; rep < 2; rep++) {
-        const int k = (tid >> 5) + rep * 8, m4 = (tid & 31) * 4;
-        const int gk = k0 + k, gm = m0 + m4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (gk < k_end) {
-          const float* p = A + (long)gk * g.lda + gm;
-#pragma unroll
-          for (int i = 0; i < 4; i++)
-            if (gm + i < g.M) v[i] = p[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) As[k][m4 + i] = v[i];
-      }
-    }
-    // ---- stage B tile [GBK][GBN]
-    if (B_KC) {
-#pragma unroll
-      for (int rep = 0; rep < 2; rep++) {
-        const int n = (tid >> 2) + rep * 64, k4 = (tid & 3) * 4;
-        const int gn = n0 + n, gk = k0 + k4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (gn < g.N) {
-          const float* p = B + (long)gn * g.ldb + gk;
-#pragma unroll
-          for (int i = 0; i < 4; i++)
-            if (gk + i < k_end) v[i] = p[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) Bs[k4 + i][n] = v[i];
-      }
-    } else {
-#pragma unroll
-      for (int rep = 0; rep < 2; rep++) {
-        const int k = (tid >> 5) + rep * 8, n4 = (tid & 31) * 4;
-        const int gk = k0 + k, gn = n0 + n4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (gk < k_end) {
-          const float* p = B + (long)gk * g.ldb + gn;
-#pragma unroll
-          for (int i = 0; i < 4; i++)
-            if (gn + i < g.N) v[i] = p[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) Bs[k][n4 + i] = v[i];
-      }
-    }
+    place_tile<A_KC>(As, tid, ra);
+    place_tile<B_KC>(Bs, tid, rb);
     __syncthreads();
+    if (k0 + GBK < k_end) {
+      fetch_tile<A_KC>(A, g.lda, m0, g.M, k0 + GBK, k_end, a_vec, tid, ra);
+      fetch_tile<B_KC>(B, g.ldb, n0, g.N, k0 + GBK, k_end, b_vec, tid, rb);
+    }
 #pragma unroll
     for (int kk = 0; kk < GBK; kk += 2) {
       const int kr = kk + (lane >> 5), c = lane & 31;
