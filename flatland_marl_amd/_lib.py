@@ -32,6 +32,7 @@ _SIGNATURES = {
     "flm_columns": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     "flm_observations_columns": [_p, _i, _i, _i, _i, _i, _p, _p],
     "flm_observations_req": [_p, _p, _p, _i, _i, _i, _i, _p, _p],
+    "flm_reorder_rails": [_p, _p, _i, _i, _i, _i, _p, _p],
     "flm_altpaths": [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     "flm_check_crash": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     "flm_update_bitmaps": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],

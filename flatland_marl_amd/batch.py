@@ -331,6 +331,17 @@ class ObservationBatch:
              ptr(out), self.stream.cuda_stream)
         return out
 
+    def reorder_rails(self, obs):
+        """Rail reordering (src/preprocessing.py:32-59) of [...,3,plane_stride] uint8 observations
+        -> (reordered copy, err [n] int32; 6 = the reference's loop would not end on that plane)."""
+        flat = obs.reshape(-1, 3, self.plane_stride)
+        n = flat.shape[0]
+        out = torch.empty_like(flat)
+        err = torch.zeros((n,), dtype=torch.int32, device=self.device)
+        call("flm_reorder_rails", ptr(flat), ptr(out), n, self.Rp, self.T1, self.plane_stride, ptr(err),
+             self.stream.cuda_stream)
+        return out.view(obs.shape), err
+
     def check_crash(self, maps, agent_sel, before_switch, next_cell, init_cell=None):
         """check_crash (src/rail_observations.py:206-230) for one selected agent per environment -> [E] int32."""
         dev = self.device

@@ -553,6 +553,78 @@ __global__ __launch_bounds__(64) void observations_req_kernel(const int8_t* __re
   *reinterpret_cast<uint4*>(o + 2 * (size_t)plane_stride) = nsum;
 }
 
+// Rail reordering, src/preprocessing.py:32-59: the rails the agent's own plane visits, in order of first
+// visit, become rows 0..ns-1 of all three planes and every other row is cleared.  One workgroup per
+// observation, out of place.  The visiting order is a chain of dependent look-ups (next time step = first
+// zero of the current rail's row, next rail = the row occupied at that step), so one thread walks it over a
+// per-time-step "first occupied row" table that all threads build; the row gather is parallel.
+// err[g] = FLM_AGENT_NONTERM where the reference never returns (the current rail stays occupied up to the
+// last time step: np.argmax of an all-False slice is 0 and its loop stops advancing).
+__global__ __launch_bounds__(256) void reorder_rails_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                            int Rp, int T1, int plane_stride,
+                                                            int32_t* __restrict__ err) {
+  extern __shared__ int rr_lds[];
+  int* first_row = rr_lds;            // [T1] first row with a non-zero entry at time step t
+  int* swap = rr_lds + T1;            // [T1 + 1]
+  __shared__ int ns_s, bad_s;
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const uint8_t* src = in + (size_t)g * 3 * plane_stride;
+  uint8_t* dst = out + (size_t)g * 3 * plane_stride;
+  for (int t = tid; t < T1; t += 256) first_row[t] = 0x7fffffff;
+  __syncthreads();
+  const int nbytes = Rp * T1;
+  for (int w = tid; w * 4 < nbytes; w += 256) {
+    uint32_t v = *reinterpret_cast<const uint32_t*>(src + (size_t)w * 4);
+    if (v == 0) continue;
+    for (int b = 0; b < 4; b++) {
+      int i = w * 4 + b;
+      if (i < nbytes && ((v >> (8 * b)) & 0xff)) {
+        int r = i / T1;
+        atomicMin(&first_row[i - r * T1], r);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int ns = 0, bad = 0, ts = 0;
+    int rail = first_row[0] == 0x7fffffff ? 0 : first_row[0];
+    if (src[(size_t)rail * T1] == 0 && T1 > 1) {      // agent not departed (:44-46)
+      ts = 1;
+      rail = first_row[1] == 0x7fffffff ? 0 : first_row[1];
+    }
+    while (src[(size_t)rail * T1 + ts] != 0) {          // :49-52
+      if (ns > T1) { bad = 1; break; }
+      swap[ns++] = rail;
+      int k = 0;
+      while (ts + k < T1 && src[(size_t)rail * T1 + ts + k] != 0) k++;
+      if (ts + k >= T1) { bad = 1; break; }
+      ts += k;
+      rail = first_row[ts] == 0x7fffffff ? 0 : first_row[ts];
+    }
+    ns_s = ns;
+    bad_s = bad;
+    err[g] = bad ? FLM_AGENT_NONTERM : 0;
+  }
+  __syncthreads();
+  const int ns = bad_s ? 0 : ns_s;
+  const bool keep = ns == 0;            // empty own plane: the reference leaves all three planes as they are
+  for (int p = 0; p < 3; p++) {
+    const uint8_t* sp = src + (size_t)p * plane_stride;
+    uint8_t* dp = dst + (size_t)p * plane_stride;
+    for (int w = tid; w * 4 < plane_stride; w += 256) {
+      uint32_t v = 0;
+      if (keep) v = *reinterpret_cast<const uint32_t*>(sp + (size_t)w * 4);
+      else if (w * 4 < ns * T1) {
+        for (int b = 0; b < 4; b++) {
+          int i = w * 4 + b, r = i / T1;
+          if (r < ns) v |= (uint32_t)sp[(size_t)swap[r] * T1 + (i - r * T1)] << (8 * b);
+        }
+      }
+      *reinterpret_cast<uint32_t*>(dp + (size_t)w * 4) = v;
+    }
+  }
+}
+
 }  // namespace flm
 
 static int launch_columns(const int32_t* path_cell, const int32_t* path_len, const int32_t* agent_flat,
@@ -717,6 +789,18 @@ extern "C" int flm_observations_req(const int8_t* maps, const int32_t* req_agent
   dim3 grid((plane_stride + 1023) / 1024, n_req);
   hipLaunchKernelGGL(flm::observations_req_kernel, grid, dim3(64), 0, (hipStream_t)stream, maps, req_agent, own_planes,
                      A, plane_stride, out);
+  FLM_CHECK_LAUNCH();
+  return FLM_OK;
+}
+
+extern "C" int flm_reorder_rails(const uint8_t* obs_in, uint8_t* obs_out, int n, int Rp, int T1, int plane_stride,
+                                 int32_t* err, void* stream) {
+  if (!obs_in || !obs_out || !err || obs_in == obs_out) return FLM_E_ARG;
+  if (n <= 0 || Rp <= 0 || T1 <= 0 || plane_stride < Rp * T1 || plane_stride % 16 != 0) return FLM_E_ARG;
+  size_t lds = sizeof(int) * (2 * (size_t)T1 + 1);
+  if (lds > 60000) return FLM_E_ARG;
+  hipLaunchKernelGGL(flm::reorder_rails_kernel, dim3(n), dim3(256), lds, (hipStream_t)stream, obs_in, obs_out, Rp, T1,
+                     plane_stride, err);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }

@@ -26,8 +26,6 @@ class ObsPreprocessor:
             raise ValueError("could not broadcast input array from shape (%d,%d) into shape (%d,%d)" % (R, T1, Rp, T1))
         if A > 255:
             raise ValueError("at most 255 agents")
-        if self.reorder_rails:
-            raise NotImplementedError("reorder_rails is not available on the device path yet")
         stride = (Rp * T1 + 15) // 16 * 16
         host = np.zeros((A + 1, stride), np.int8)
         host[:A, :Rp * T1].reshape(A, Rp, T1)[:, :R] = maps
@@ -37,7 +35,19 @@ class ObsPreprocessor:
         out = torch.empty((1, 3, stride), dtype=torch.uint8, device=self.device)
         call("flm_observations_req", ptr(dev), ptr(req), ptr(dev[A:]), 1, 1, A, stride, ptr(out),
              torch.cuda.current_stream(self.device).cuda_stream)
+        if self.reorder_rails:
+            # src/preprocessing.py:32-59; as there, the caller's bitmap ends up reordered too
+            res = torch.empty_like(out)
+            err = torch.zeros((1,), dtype=torch.int32, device=self.device)
+            call("flm_reorder_rails", ptr(out), ptr(res), 1, Rp, T1, stride, ptr(err),
+                 torch.cuda.current_stream(self.device).cuda_stream)
+            if int(err.item()):
+                raise RuntimeError("reorder_rails: agent %d stays on one rail up to the last predicted step; "
+                                   "the reference's loop (src/preprocessing.py:49-52) never ends here" % handle)
+            out = res
         o = out[0, :, :Rp * T1].cpu().numpy()
+        if self.reorder_rails and bitmap.flags.writeable:
+            bitmap[...] = o[0].view(np.int8).reshape(Rp, T1)[:bitmap.shape[0]]
         state = o.astype(np.float64)
         state[0] = o[0].view(np.int8)
         return state.reshape(3 * Rp, T1)

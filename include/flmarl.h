@@ -40,6 +40,7 @@ extern "C" {
 #define FLM_AGENT_KEY_ERROR 3     /* src/rail_observations.py:353, :365, :382 */
 #define FLM_AGENT_ASSERT_ERROR 4  /* src/rail_observations.py:395; src/utils/shortest_path.py:108, :125 */
 #define FLM_AGENT_OVERFLOW 5      /* more alternatives / longer path than the caller's capacity */
+#define FLM_AGENT_NONTERM 6       /* src/preprocessing.py:49-52 would loop forever on this plane */
 
 #define FLM_GRAPH_ERR_NODES 1     /* counts[3] bits: capacity exceeded */
 #define FLM_GRAPH_ERR_RAILS 2
@@ -168,6 +169,16 @@ int flm_observations_columns(const int16_t* cols, int E, int A, int Rp, int T1, 
  *   src/preprocessing.py:25-26); out [n_req,3,plane_stride] uint8.  n_req <= 65535, A <= 255. */
 int flm_observations_req(const int8_t* maps, const int32_t* req_agent, const int8_t* own_planes, int n_req, int E,
                          int A, int plane_stride, uint8_t* out, void* stream);
+
+/* Rail reordering of finished observations.
+ * Replaces ObsPreprocessor._reorder_rails / _swap_rails, src/preprocessing.py:32-59 (enabled by
+ * --reorder-rails, src/main.py:395): the rails the own plane (plane 0) visits, in order of first visit,
+ * become rows 0..k-1 of all three planes; every other row is cleared.  Out of place: obs_in != obs_out,
+ * both [n,3,plane_stride] uint8 with planes of Rp rows x T1 bytes.
+ *   err [n] int32: 0, or FLM_AGENT_NONTERM when the visited rail stays occupied up to the last time step
+ *   (the reference's loop never ends there); such an observation is copied unchanged. */
+int flm_reorder_rails(const uint8_t* obs_in, uint8_t* obs_out, int n, int Rp, int T1, int plane_stride,
+                      int32_t* err, void* stream);
 
 /* Alternative paths of agents that stand in front of a switch.
  * Replaces get_altpaths, src/utils/shortest_path.py:92-163 (called through
