@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=1, help="split the batch into this many sub-batches")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the sub-batches are spread over")
     ap.add_argument("--obs-lds-pad", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--obs-tile", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--obs-serial", type=int, default=1,
                     help="1: observation kernels run one after the other on the main stream after the other stages")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -88,6 +89,7 @@ def main():
     import flatland_marl_amd as fm
     from flatland_marl_amd import parallel
     from flatland_marl_amd.synthetic import make_batch
+    from flatland_marl_amd.batch import plane_stride_for
     parallel.init_distributed("nccl", device)
 
     names, E, A, depth, desc = WORKLOADS[args.workload]
@@ -100,6 +102,9 @@ def main():
     if args.obs_lds_pad:
         from flatland_marl_amd import _lib
         _lib.call("flm_dev_set_option", 3, args.obs_lds_pad)
+    if args.obs_tile:
+        from flatland_marl_amd import _lib
+        _lib.call("flm_dev_set_option", 4, args.obs_tile)
     n_chunks = max(1, min(args.chunks, E))
     streams = [torch.cuda.Stream(device=device) for _ in range(max(1, args.streams))] if args.streams > 1 or n_chunks > 1 \
         else [torch.cuda.current_stream(device)]
@@ -117,7 +122,7 @@ def main():
     for b in batches:
         b.max_rails = Rp
         b.Rp = Rp
-        b.plane_stride = (Rp * b.T1 + 15) // 16 * 16
+        b.plane_stride = plane_stride_for(Rp, b.T1)
         with torch.cuda.stream(b.stream):
             b.reset_fused(sync=True)         # sizes the rail axis (one host read-back), allocates every buffer
     torch.cuda.synchronize()

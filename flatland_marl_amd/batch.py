@@ -32,6 +32,12 @@ def _dev_i32(x, device):
     return torch.as_tensor(np.ascontiguousarray(x, dtype=np.int32), device=device)
 
 
+def plane_stride_for(Rp, T1):
+    """Bytes between consecutive planes: Rp*T1 rounded up to 256, so that every plane starts on a cache-line
+    boundary and whole-wave 1 KiB stores never straddle one (the C ABI itself only asks for a multiple of 16)."""
+    return (Rp * T1 + 255) // 256 * 256
+
+
 class ObservationBatch:
     def __init__(self, grid, start_rc, direction, target_rc, speed, depth, max_rails=None, status=None,
                  device="cuda:0", stream=None):
@@ -134,7 +140,7 @@ class ObservationBatch:
             # the reference fails in _fill_padding (src/preprocessing.py:19) with a numpy broadcast error
             raise ValueError("could not broadcast: an environment has %d rails > max_rails=%d" % (need, self.max_rails))
         self.Rp = max(need, 1) if self.max_rails is None else int(self.max_rails)
-        self.plane_stride = (self.Rp * self.T1 + 15) // 16 * 16
+        self.plane_stride = plane_stride_for(self.Rp, self.T1)
         return self
 
     def check_graph(self):

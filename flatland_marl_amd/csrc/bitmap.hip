@@ -451,41 +451,41 @@ __global__ __launch_bounds__(1024) void observations_kernel(const int8_t* __rest
   }
 }
 
-// Observations straight from the column form (no dense input planes): a workgroup owns 1 KiB of plane
+// Observations straight from the column form (no dense input planes): a workgroup owns CH KiB of plane
 // positions of one environment.  Every wave walks the columns of its agents once, keeps the few entries
 // that fall into the tile in registers and counts them into two packed-byte totals in LDS.  After the
 // barrier it writes, per agent, the own plane (zeros except those entries, staged through a per-wave LDS
 // tile) and total-minus-self for both signs.  The kernel only writes to HBM: 3 bytes per position and agent.
-template <int APW, int KT>
+// Every workgroup scans all A*T1 column entries of its environment, so a larger tile (CH) pays when there
+// are many of them.
+template <int APW, int KT, int CH>
 __global__ __launch_bounds__(1024) void observations_columns_kernel(const int16_t* __restrict__ cols, int A, int T1,
                                                                     int plane_stride, uint8_t* __restrict__ obs) {
   extern __shared__ __attribute__((aligned(16))) unsigned lds_u[];
-  unsigned* tot_pos = lds_u;          // [256] packed bytes
-  unsigned* tot_neg = lds_u + 256;    // [256]
+  constexpr int TILE = 1024 * CH;
+  unsigned* tot_pos = lds_u;                // [TILE/4] packed bytes
+  unsigned* tot_neg = lds_u + TILE / 4;     // [TILE/4]
   const int nw = blockDim.x >> 6;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  unsigned char* own = reinterpret_cast<unsigned char*>(lds_u + 512) + wave * 1024;   // per-wave tile
+  unsigned char* own = reinterpret_cast<unsigned char*>(lds_u + TILE / 2) + wave * TILE;   // per-wave tile
   const int e = blockIdx.y;
-  const int p0 = blockIdx.x * 1024;
-  for (int i = threadIdx.x; i < 512; i += blockDim.x) lds_u[i] = 0;
+  const int p0 = blockIdx.x * TILE;
+  for (int i = threadIdx.x; i < TILE / 2; i += blockDim.x) lds_u[i] = 0;
   __syncthreads();
-  int hit_p[APW][KT];   // offset inside the tile, -1 = none
-  int hit_v[APW][KT];   // +1 / -1
+  int hit[APW][KT];     // (offset inside the tile) * 2 + (sign > 0), -1 = none
 #pragma unroll
   for (int i = 0; i < APW; i++) {
     const int a = wave + i * nw;
 #pragma unroll
     for (int k = 0; k < KT; k++) {
       const int t = lane + 64 * k;
-      hit_p[i][k] = -1;
-      hit_v[i][k] = 0;
+      hit[i][k] = -1;
       if (a < A && t < T1) {
         const int c = cols[((size_t)e * A + a) * T1 + t];
         if (c >= 0) {
           const int p = (c >> 1) * T1 + t - p0;
-          if (p >= 0 && p < 1024) {
-            hit_p[i][k] = p;
-            hit_v[i][k] = (c & 1) ? 1 : -1;
+          if (p >= 0 && p < TILE) {
+            hit[i][k] = p * 2 + (c & 1);
             atomicAdd(((c & 1) ? tot_pos : tot_neg) + (p >> 2), 1u << ((p & 3) * 8));
           }
         }
@@ -493,10 +493,12 @@ __global__ __launch_bounds__(1024) void observations_columns_kernel(const int16_
     }
   }
   __syncthreads();
-  const size_t off = (size_t)p0 + (size_t)lane * 16;
-  const bool active = off < (size_t)plane_stride;
-  const uint4 ptot = reinterpret_cast<const uint4*>(tot_pos)[lane];
-  const uint4 ntot = reinterpret_cast<const uint4*>(tot_neg)[lane];
+  uint4 ptot[CH], ntot[CH];
+#pragma unroll
+  for (int c = 0; c < CH; c++) {
+    ptot[c] = reinterpret_cast<const uint4*>(tot_pos)[c * 64 + lane];
+    ntot[c] = reinterpret_cast<const uint4*>(tot_neg)[c * 64 + lane];
+  }
   const uint4 zero = make_uint4(0, 0, 0, 0);
 #pragma unroll
   for (int i = 0; i < APW; i++) {
@@ -504,23 +506,31 @@ __global__ __launch_bounds__(1024) void observations_columns_kernel(const int16_
     if (a >= A) continue;   // wave-uniform
     bool any = false;
 #pragma unroll
-    for (int k = 0; k < KT; k++) any |= hit_p[i][k] >= 0;
-    uint4 mine = zero;
+    for (int k = 0; k < KT; k++) any |= hit[i][k] >= 0;
+    uint4 mine[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) mine[c] = zero;
     if (__ballot(any)) {   // wave-uniform: this agent has entries in the tile
-      reinterpret_cast<uint4*>(own)[lane] = zero;
+#pragma unroll
+      for (int c = 0; c < CH; c++) reinterpret_cast<uint4*>(own)[c * 64 + lane] = zero;
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int k = 0; k < KT; k++)
-        if (hit_p[i][k] >= 0) own[hit_p[i][k]] = (unsigned char)hit_v[i][k];
+        if (hit[i][k] >= 0) own[hit[i][k] >> 1] = (hit[i][k] & 1) ? (unsigned char)1 : (unsigned char)0xff;
       __builtin_amdgcn_wave_barrier();
-      mine = reinterpret_cast<const uint4*>(own)[lane];
+#pragma unroll
+      for (int c = 0; c < CH; c++) mine[c] = reinterpret_cast<const uint4*>(own)[c * 64 + lane];
       __builtin_amdgcn_wave_barrier();
     }
-    if (active) {
-      uint8_t* o = obs + ((size_t)e * A + a) * 3 * plane_stride + off;
-      store16<true>(o, mine);
-      store16<true>(o + plane_stride, sub4(ptot, pos_bits4(mine)));
-      store16<true>(o + 2 * (size_t)plane_stride, sub4(ntot, neg_bits4(mine)));
+    uint8_t* o = obs + ((size_t)e * A + a) * 3 * plane_stride;
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+      const size_t off = (size_t)p0 + (size_t)c * 1024 + (size_t)lane * 16;
+      if (off < (size_t)plane_stride) {
+        store16<true>(o + off, mine[c]);
+        store16<true>(o + plane_stride + off, sub4(ptot[c], pos_bits4(mine[c])));
+        store16<true>(o + 2 * (size_t)plane_stride + off, sub4(ntot[c], neg_bits4(mine[c])));
+      }
     }
   }
 }
@@ -739,30 +749,41 @@ extern "C" int flm_observations(const int8_t* maps, const int8_t* own, int E, in
             : launch_obs_apw<4, false>(maps, own, E, A, plane_stride, obs, nw, stream);
 }
 
-template <int APW, int KT>
+template <int APW, int KT, int CH>
 static int launch_obs_cols(const int16_t* cols, int E, int A, int T1, int plane_stride, uint8_t* obs, int nw,
                            hipStream_t stream) {
-  dim3 grid((plane_stride + 1023) / 1024, E);
-  size_t lds = 2048 + 1024 * (size_t)nw + (size_t)g_flm_dev_opt[3] * 1024;   // dev option 3: LDS padding in KiB (limits workgroups per CU)
-  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(flm::observations_columns_kernel<APW, KT>),
+  dim3 grid((plane_stride + 1024 * CH - 1) / (1024 * CH), E);
+  size_t lds = (size_t)CH * (2048 + 1024 * (size_t)nw) + (size_t)g_flm_dev_opt[3] * 1024;   // dev option 3: LDS padding in KiB (limits workgroups per CU)
+  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(flm::observations_columns_kernel<APW, KT, CH>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return FLM_E_LAUNCH;
-  hipLaunchKernelGGL((flm::observations_columns_kernel<APW, KT>), grid, dim3(nw * 64), lds, stream, cols, A, T1,
+  hipLaunchKernelGGL((flm::observations_columns_kernel<APW, KT, CH>), grid, dim3(nw * 64), lds, stream, cols, A, T1,
                      plane_stride, obs);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }
 
-template <int KT>
+template <int KT, int CH>
 static int launch_obs_cols_apw(const int16_t* cols, int E, int A, int T1, int plane_stride, uint8_t* obs, int nw,
                                hipStream_t stream) {
   int apw = (A + nw - 1) / nw;
-  if (apw <= 1) return launch_obs_cols<1, KT>(cols, E, A, T1, plane_stride, obs, nw, stream);
-  if (apw <= 2) return launch_obs_cols<2, KT>(cols, E, A, T1, plane_stride, obs, nw, stream);
-  if (apw <= 4) return launch_obs_cols<4, KT>(cols, E, A, T1, plane_stride, obs, nw, stream);
-  if (apw <= 8) return launch_obs_cols<8, KT>(cols, E, A, T1, plane_stride, obs, nw, stream);
-  if (apw <= 16) return launch_obs_cols<16, KT>(cols, E, A, T1, plane_stride, obs, nw, stream);
+  if (apw <= 1) return launch_obs_cols<1, KT, CH>(cols, E, A, T1, plane_stride, obs, nw, stream);
+  if (apw <= 2) return launch_obs_cols<2, KT, CH>(cols, E, A, T1, plane_stride, obs, nw, stream);
+  if (apw <= 4) return launch_obs_cols<4, KT, CH>(cols, E, A, T1, plane_stride, obs, nw, stream);
+  if (apw <= 8) return launch_obs_cols<8, KT, CH>(cols, E, A, T1, plane_stride, obs, nw, stream);
+  if (apw <= 16) return launch_obs_cols<16, KT, CH>(cols, E, A, T1, plane_stride, obs, nw, stream);
   return FLM_E_ARG;
+}
+
+template <int CH>
+static int launch_obs_cols_kt(const int16_t* cols, int E, int A, int T1, int plane_stride, uint8_t* obs, int nw,
+                              hipStream_t stream) {
+  int kt = (T1 + 63) / 64;
+  if (kt <= 1) return launch_obs_cols_apw<1, CH>(cols, E, A, T1, plane_stride, obs, nw, stream);
+  if (kt <= 2) return launch_obs_cols_apw<2, CH>(cols, E, A, T1, plane_stride, obs, nw, stream);
+  if (kt <= 3) return launch_obs_cols_apw<3, CH>(cols, E, A, T1, plane_stride, obs, nw, stream);
+  if (kt <= 5) return launch_obs_cols_apw<5, CH>(cols, E, A, T1, plane_stride, obs, nw, stream);
+  return launch_obs_cols_apw<8, CH>(cols, E, A, T1, plane_stride, obs, nw, stream);
 }
 
 extern "C" int flm_observations_columns(const int16_t* cols, int E, int A, int Rp, int T1, int plane_stride,
@@ -773,12 +794,11 @@ extern "C" int flm_observations_columns(const int16_t* cols, int E, int A, int R
     return FLM_E_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   int nw = A < 16 ? A : 16;
-  int kt = (T1 + 63) / 64;
-  if (kt <= 1) return launch_obs_cols_apw<1>(cols, E, A, T1, plane_stride, obs, nw, stream);
-  if (kt <= 2) return launch_obs_cols_apw<2>(cols, E, A, T1, plane_stride, obs, nw, stream);
-  if (kt <= 3) return launch_obs_cols_apw<3>(cols, E, A, T1, plane_stride, obs, nw, stream);
-  if (kt <= 5) return launch_obs_cols_apw<5>(cols, E, A, T1, plane_stride, obs, nw, stream);
-  return launch_obs_cols_apw<8>(cols, E, A, T1, plane_stride, obs, nw, stream);
+  // tile size: 1 KiB while an environment has few column entries, 2 or 4 KiB when scanning them dominates
+  int ch = g_flm_dev_opt[4] ? g_flm_dev_opt[4] : ((long)A * T1 >= 32768 ? 4 : (long)A * T1 >= 12288 ? 2 : 1);
+  if (ch >= 4) return launch_obs_cols_kt<4>(cols, E, A, T1, plane_stride, obs, nw, stream);
+  if (ch >= 2) return launch_obs_cols_kt<2>(cols, E, A, T1, plane_stride, obs, nw, stream);
+  return launch_obs_cols_kt<1>(cols, E, A, T1, plane_stride, obs, nw, stream);
 }
 
 extern "C" int flm_observations_req(const int8_t* maps, const int32_t* req_agent, const int8_t* own_planes, int n_req,
