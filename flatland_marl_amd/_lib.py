@@ -33,6 +33,10 @@ _SIGNATURES = {
     "flm_observations_columns": [_p, _i, _i, _i, _i, _i, _p, _p],
     "flm_observations_req": [_p, _p, _p, _i, _i, _i, _i, _p, _p],
     "flm_reorder_rails": [_p, _p, _i, _i, _i, _i, _p, _p],
+    "flm_observations_req_columns": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
+    "flm_rollout_classify": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
+    "flm_rollout_apply": [_p] * 18 + [_i] * 6 + [_p, _p, _p, _p],
+    "flm_env_step": [_p] * 13 + [_i] * 4 + [_p, _p, _p, _p],
     "flm_altpaths": [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     "flm_check_crash": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     "flm_update_bitmaps": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],

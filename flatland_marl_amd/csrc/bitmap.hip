@@ -563,6 +563,50 @@ __global__ __launch_bounds__(64) void observations_req_kernel(const int8_t* __re
   *reinterpret_cast<uint4*>(o + 2 * (size_t)plane_stride) = nsum;
 }
 
+// Observation of selected agents straight from the column form: request g asks for agent req_agent[g]
+// (= e*A + a); the plane shown as its own comes from own_cols[g] when given (an alternative), else from the
+// agent's own columns; the heat planes sum the other agents' columns.  One workgroup per (1 KiB tile, request).
+__global__ __launch_bounds__(256) void observations_req_columns_kernel(const int16_t* __restrict__ cols,
+                                                                       const int32_t* __restrict__ req_agent,
+                                                                       const int16_t* __restrict__ own_cols, int A, int T1,
+                                                                       int plane_stride, uint8_t* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) unsigned tile[3][256];   // own plane, positive heat, negative heat (packed bytes)
+  const int g = blockIdx.y, tid = threadIdx.x;
+  const int ga = req_agent[g];
+  const int e = ga / A, a = ga - e * A;
+  const int p0 = blockIdx.x * 1024;
+  tile[0][tid] = 0;
+  tile[1][tid] = 0;
+  tile[2][tid] = 0;
+  __syncthreads();
+  const int16_t* env = cols + (size_t)e * A * T1;
+  for (int i = tid; i < A * T1; i += 256) {
+    const int o = i / T1, t = i - o * T1;
+    if (o == a) continue;
+    const int c = env[i];
+    if (c < 0) continue;
+    const int p = (c >> 1) * T1 + t - p0;
+    if (p >= 0 && p < 1024) atomicAdd(&tile[(c & 1) ? 1 : 2][p >> 2], 1u << ((p & 3) * 8));
+  }
+  const int16_t* src = own_cols ? own_cols + (size_t)g * T1 : env + (size_t)a * T1;
+  for (int t = tid; t < T1; t += 256) {
+    const int c = src[t];
+    if (c < 0) continue;
+    const int p = (c >> 1) * T1 + t - p0;
+    if (p >= 0 && p < 1024) reinterpret_cast<unsigned char*>(tile[0])[p] = (c & 1) ? (unsigned char)1 : (unsigned char)0xff;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const size_t off = (size_t)p0 + (size_t)tid * 16;
+    if (off < (size_t)plane_stride) {
+      uint8_t* o = out + (size_t)g * 3 * plane_stride + off;
+      *reinterpret_cast<uint4*>(o) = reinterpret_cast<const uint4*>(tile[0])[tid];
+      *reinterpret_cast<uint4*>(o + plane_stride) = reinterpret_cast<const uint4*>(tile[1])[tid];
+      *reinterpret_cast<uint4*>(o + 2 * (size_t)plane_stride) = reinterpret_cast<const uint4*>(tile[2])[tid];
+    }
+  }
+}
+
 // Rail reordering, src/preprocessing.py:32-59: the rails the agent's own plane visits, in order of first
 // visit, become rows 0..ns-1 of all three planes and every other row is cleared.  One workgroup per
 // observation, out of place.  The visiting order is a chain of dependent look-ups (next time step = first
@@ -809,6 +853,20 @@ extern "C" int flm_observations_req(const int8_t* maps, const int32_t* req_agent
   dim3 grid((plane_stride + 1023) / 1024, n_req);
   hipLaunchKernelGGL(flm::observations_req_kernel, grid, dim3(64), 0, (hipStream_t)stream, maps, req_agent, own_planes,
                      A, plane_stride, out);
+  FLM_CHECK_LAUNCH();
+  return FLM_OK;
+}
+
+extern "C" int flm_observations_req_columns(const int16_t* cols, const int32_t* req_agent, const int16_t* own_cols,
+                                            int n_req, int E, int A, int Rp, int T1, int plane_stride, uint8_t* out,
+                                            void* stream) {
+  if (!cols || !req_agent || !out) return FLM_E_ARG;
+  if (n_req <= 0 || n_req > 65535 || E <= 0 || A <= 0 || A > 255 || Rp <= 0 || T1 <= 0 || plane_stride % 16 != 0 ||
+      (long long)plane_stride < (long long)Rp * T1)
+    return FLM_E_ARG;
+  dim3 grid((plane_stride + 1023) / 1024, n_req);
+  hipLaunchKernelGGL(flm::observations_req_columns_kernel, grid, dim3(256), 0, (hipStream_t)stream, cols, req_agent,
+                     own_cols, A, T1, plane_stride, out);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }

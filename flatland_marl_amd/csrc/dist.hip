@@ -21,6 +21,14 @@ namespace flm {
 
 #define FLM_NONE16 0xFFFFu
 
+// Orders the LDS accesses of one wave's lanes: a wave's LDS operations complete in program order, so it is
+// enough to keep the compiler from moving them across this point.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
+
 __global__ __launch_bounds__(1024) void chain_index_kernel(
     const uint16_t* __restrict__ grid_all, const int32_t* __restrict__ cell_idx_all,
     const int32_t* __restrict__ n_cells_all, const int32_t* __restrict__ target_cell, int A, int H, int W, int capCells,
@@ -168,8 +176,10 @@ __global__ __launch_bounds__(1024) void chain_index_kernel(
 }
 
 // One workgroup per (environment, 32 target slots).  LDS per anchor: its forward edges, its distance for
-// each of the 32 targets, its predecessors (reverse edges) and a 32-bit "dirty" set.  Work lists hold
-// (anchor, target) pairs packed in 16 bits.  A round has two phases, one thread per pair:
+// each of the 32 targets, its predecessors (reverse edges) and a 32-bit "dirty" set.  Targets are
+// independent problems, so each of the 8 waves owns 4 of them and iterates on its own, without workgroup
+// barriers (a wave's LDS operations complete in program order).  Per wave, work lists hold (anchor, target)
+// pairs packed in 16 bits.  A round has two phases, one lane per pair:
 //   1. every pair whose label got smaller marks the same target dirty at the anchor's predecessors; a
 //      pair that becomes dirty is appended once (the LDS atomic OR returns the previous set);
 //   2. every dirty pair re-evaluates its label as the minimum over the anchor's moves and, if it got
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(1024) void chain_index_kernel(
 // for after the rounds by sweeping all labels until nothing changes (labels are always lengths of real
 // paths, so the sweep converges to the same shortest distances).
 #define FLM_DC_THREADS 512
-#define FLM_DC_LIST 2048
+#define FLM_DC_LIST 512    // pairs per wave and list
 #define FLM_DA_ROW 34   // uint16 per anchor row: 32 targets + 2 of padding, so that rows start on different LDS banks
 __global__ __launch_bounds__(FLM_DC_THREADS) void distance_chain_kernel(
     const uint16_t* __restrict__ root_all, const uint16_t* __restrict__ steps_all, const uint32_t* __restrict__ edges_all,
@@ -187,7 +197,8 @@ __global__ __launch_bounds__(FLM_DC_THREADS) void distance_chain_kernel(
     const int32_t* __restrict__ n_slots, int A, int HW, int capCells, int capAnch, int ldsAnch,
     uint16_t* __restrict__ dist_all, int32_t* __restrict__ counts_all, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ int s_cnt[4];   // [0],[1]: changed-list sizes (by round parity), [2]: dirty-list size, [3]: pairs lost
+  __shared__ int s_cnt[FLM_DC_THREADS / 64][2];   // per wave: changed-list size, dirty-list size
+  __shared__ int s_lost;                          // some pair did not fit a list
   const int e = blockIdx.y, tid = threadIdx.x, T = FLM_DC_THREADS;
   const int ns = n_slots[e];
   const int base_slot = blockIdx.x * 32;
@@ -205,9 +216,7 @@ __global__ __launch_bounds__(FLM_DC_THREADS) void distance_chain_kernel(
   unsigned* dirty = reinterpret_cast<unsigned*>(da + (size_t)ldsAnch * FLM_DA_ROW);   // [ldsAnch]
   unsigned* rev_off = dirty + ldsAnch;                               // [ldsAnch + 1]
   uint16_t* rev_list = reinterpret_cast<uint16_t*>(rev_off + ldsAnch + 1);    // [4*ldsAnch]
-  uint16_t* list_c0 = rev_list + 4 * (size_t)ldsAnch;                // changed pairs, two buffers
-  uint16_t* list_c1 = list_c0 + FLM_DC_LIST;
-  uint16_t* list_d = list_c1 + FLM_DC_LIST;                          // dirty pairs
+  uint16_t* lists = rev_list + 4 * (size_t)ldsAnch;                  // per wave: changed pairs, dirty pairs
   const uint16_t* root = root_all + (size_t)e * capS;
   const uint16_t* steps = steps_all + (size_t)e * capS;
 
@@ -216,7 +225,8 @@ __global__ __launch_bounds__(FLM_DC_THREADS) void distance_chain_kernel(
     dirty[a] = 0;     // first used as in-degree counter / fill cursor while the reverse lists are built
   }
   for (int i = tid; i < NA * FLM_DA_ROW; i += T) da[i] = (uint16_t)FLM_NONE16;
-  if (tid < 4) s_cnt[tid] = 0;
+  if (tid < 2 * (T / 64)) (&s_cnt[0][0])[tid] = 0;
+  if (tid == 0) s_lost = 0;
   __syncthreads();
   if (dbg & 8) return;
   // reverse adjacency (predecessor anchors)
@@ -259,77 +269,82 @@ __global__ __launch_bounds__(FLM_DC_THREADS) void distance_chain_kernel(
   __syncthreads();
   for (int a = tid; a < NA; a += T) dirty[a] = 0;
   __syncthreads();
-  // sources: the four states of each target cell
-  if (tid < nslot * 4) {
-    const int j = tid >> 2, h = tid & 3;
-    const int tcell = slot_target[(size_t)e * A + base_slot + j];
-    if (tcell >= 0 && tcell < HW) {
-      const int ci = cell_idx_all[(size_t)e * HW + tcell];
-      if (ci >= 0) {
-        const unsigned a = root[ci * 4 + h];   // target states are anchors: root = own anchor number
-        if (a != FLM_NONE16) {
-          da[a * FLM_DA_ROW + j] = 0;
-          list_c0[atomicAdd(&s_cnt[0], 1)] = (uint16_t)(a | (j << 11));
+  {
+    const int w = tid >> 6, lane = tid & 63;
+    uint16_t* lc = lists + (size_t)w * 2 * FLM_DC_LIST;   // changed pairs
+    uint16_t* ld = lc + FLM_DC_LIST;                      // dirty pairs
+    int* cnt = s_cnt[w];
+    // sources: the four states of each target cell (this wave's targets are w, w+8, w+16, w+24)
+    if (lane < 16) {
+      const int j = w + 8 * (lane >> 2), h = lane & 3;
+      if (j < nslot) {
+        const int tcell = slot_target[(size_t)e * A + base_slot + j];
+        if (tcell >= 0 && tcell < HW) {
+          const int ci = cell_idx_all[(size_t)e * HW + tcell];
+          if (ci >= 0) {
+            const unsigned a = root[ci * 4 + h];   // target states are anchors: root = own anchor number
+            if (a != FLM_NONE16) {
+              da[a * FLM_DA_ROW + j] = 0;
+              lc[atomicAdd(&cnt[0], 1)] = (uint16_t)(a | (j << 11));
+            }
+          }
         }
       }
     }
-  }
-  __syncthreads();
-  for (int round = 0; round < ((dbg & 1) ? 0 : 65536); round++) {
-    const uint16_t* lc = (round & 1) ? list_c1 : list_c0;
-    uint16_t* lc_next = (round & 1) ? list_c0 : list_c1;
-    const int nc = min(s_cnt[round & 1], FLM_DC_LIST);
-    if (nc == 0) {
-      if ((dbg & 16) && tid == 0) counts_all[e * 4 + 2] = round;
-      break;
-    }
-    // phase 1: predecessors of the changed pairs become dirty
-    for (int i = tid; i < nc; i += T) {
-      const unsigned pr = lc[i];
-      const unsigned r = pr & 0x7FFu, bit = 1u << (pr >> 11);
-      for (unsigned q = rev_off[r]; q < rev_off[r + 1]; q++) {
-        const unsigned b = rev_list[q];
-        if (!(atomicOr(&dirty[b], bit) & bit)) {
-          const int pos = atomicAdd(&s_cnt[2], 1);
-          if (pos < FLM_DC_LIST) list_d[pos] = (uint16_t)(b | (pr & 0xF800u));
-          else s_cnt[3] = 1;
+    wave_sync();
+    for (int round = 0; round < ((dbg & 1) ? 0 : 65536); round++) {
+      const int nc = min(cnt[0], FLM_DC_LIST);
+      if (nc == 0) {
+        if ((dbg & 16) && tid == 0) counts_all[e * 4 + 2] = round;
+        break;
+      }
+      // phase 1: predecessors of the changed pairs become dirty
+      for (int i = lane; i < nc; i += 64) {
+        const unsigned pr = lc[i];
+        const unsigned r = pr & 0x7FFu, bit = 1u << (pr >> 11);
+        for (unsigned q = rev_off[r]; q < rev_off[r + 1]; q++) {
+          const unsigned b = rev_list[q];
+          if (!(atomicOr(&dirty[b], bit) & bit)) {
+            const int pos = atomicAdd(&cnt[1], 1);
+            if (pos < FLM_DC_LIST) ld[pos] = (uint16_t)(b | (pr & 0xF800u));
+            else s_lost = 1;
+          }
         }
       }
-    }
-    __syncthreads();
-    const int nd = min(s_cnt[2], FLM_DC_LIST);
-    if (tid == 0) s_cnt[(round + 1) & 1] = 0;
-    __syncthreads();
-    // phase 2: re-evaluate the dirty pairs
-    for (int i = tid; i < nd; i += T) {
-      const unsigned pr = list_d[i];
-      const unsigned b = pr & 0x7FFu, j = pr >> 11;
-      const uint4 eb = ed[b];
-      const unsigned ev[4] = {eb.x, eb.y, eb.z, eb.w};
-      const unsigned cur = da[b * FLM_DA_ROW + j];
-      unsigned best = cur;
+      wave_sync();
+      const int nd = min(cnt[1], FLM_DC_LIST);
+      wave_sync();
+      if (lane == 0) { cnt[0] = 0; cnt[1] = 0; }
+      wave_sync();
+      // phase 2: re-evaluate the dirty pairs; the changed list has been consumed and is refilled
+      for (int i = lane; i < nd; i += 64) {
+        const unsigned pr = ld[i];
+        const unsigned b = pr & 0x7FFu, j = pr >> 11;
+        const uint4 eb = ed[b];
+        const unsigned ev[4] = {eb.x, eb.y, eb.z, eb.w};
+        const unsigned cur = da[b * FLM_DA_ROW + j];
+        unsigned best = cur;
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        if (ev[k] == 0xFFFFFFFFu) continue;
-        const unsigned d = da[(ev[k] & 0xFFFFu) * FLM_DA_ROW + j];
-        if (d == FLM_NONE16) continue;
-        const unsigned cand = d + (ev[k] >> 16);
-        if (cand < best) best = cand;
+        for (int k = 0; k < 4; k++) {
+          if (ev[k] == 0xFFFFFFFFu) continue;
+          const unsigned d = da[(ev[k] & 0xFFFFu) * FLM_DA_ROW + j];
+          if (d == FLM_NONE16) continue;
+          const unsigned cand = d + (ev[k] >> 16);
+          if (cand < best) best = cand;
+        }
+        atomicAnd(&dirty[b], ~(1u << j));
+        if (best < cur) {
+          da[b * FLM_DA_ROW + j] = (uint16_t)(best > 0xFFFEu ? 0xFFFEu : best);
+          const int pos = atomicAdd(&cnt[0], 1);
+          if (pos < FLM_DC_LIST) lc[pos] = (uint16_t)pr;
+          else s_lost = 1;
+        }
       }
-      atomicAnd(&dirty[b], ~(1u << j));
-      if (best < cur) {
-        da[b * FLM_DA_ROW + j] = (uint16_t)(best > 0xFFFEu ? 0xFFFEu : best);
-        const int pos = atomicAdd(&s_cnt[(round + 1) & 1], 1);
-        if (pos < FLM_DC_LIST) lc_next[pos] = (uint16_t)pr;
-        else s_cnt[3] = 1;
-      }
+      wave_sync();
     }
-    __syncthreads();
-    if (tid == 0) s_cnt[2] = 0;
-    // (the next round starts with a read of s_cnt[(round+1)&1]; the barrier above ordered its writes)
   }
   __syncthreads();
-  if (s_cnt[3]) {
+  if (s_lost) {
     // some pairs did not fit a list: sweep all labels until none changes
     const int j = tid & 31;
     for (int it = 0; it <= NA * 32; it++) {
@@ -424,7 +439,7 @@ extern "C" int flm_distance_chains(const uint16_t* root, const uint16_t* steps, 
     return FLM_E_ARG;
   if (ldsAnch > 2047) return FLM_E_ARG;   // anchors are packed in 11 bits on the work lists
   if (capCells & 1) return FLM_E_ARG;     // 16-byte row stores
-  size_t lds = (size_t)ldsAnch * (16 + 2 * FLM_DA_ROW + 4 + 4 + 8) + 16 + 3 * FLM_DC_LIST * 2;
+  size_t lds = (size_t)ldsAnch * (16 + 2 * FLM_DA_ROW + 4 + 4 + 8) + 16 + (FLM_DC_THREADS / 64) * 2 * FLM_DC_LIST * 2;
   if (lds > 160 * 1024 - 512) return FLM_E_ARG;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(flm::distance_chain_kernel),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

@@ -188,7 +188,7 @@ __device__ bool blk_headon_crash(const EnvMaps& m, const int32_t* status, const 
                                  int* s_tmp) {
   int last;
   int le = blk_last_train_on_rail(m, status, tpc, a, rail, s_tmp, &last);
-  if (le > 0) return m.plane(last)[(size_t)rail * m.T1 + le - 1] != dir;
+  if (le > 0) return (le - 1 < m.T1 ? m.plane(last)[(size_t)rail * m.T1 + le - 1] : 0) != dir;
   return false;
 }
 

@@ -1,0 +1,527 @@
+// Batched rollout step on the column form of the occupancy planes.
+//
+// A plane holds at most one entry per time step, so an agent's plane is kept as T1 int16 "columns":
+// rail*2 + (sign > 0), or -1 for an empty column.  Every bookkeeping rule of the training loop (shift by
+// one step, delay behind the last train of the next rail, head-on crash checks) reads or moves whole
+// columns, so a rollout step touches A*T1*2 bytes per environment instead of A*Rp*T1.
+//
+// One wave per environment walks the agents in handle order, exactly as the sequential loop does: an
+// agent's checks see the planes of lower-numbered agents already updated for this step and those of
+// higher-numbered agents not yet.
+#include "flm_common.h"
+
+namespace flm {
+
+#define FLM_STEP_KT 8   // T1 <= 64 * FLM_STEP_KT
+
+__device__ __forceinline__ bool on_rail(int c, int rail) { return c >= 0 && (c >> 1) == rail; }
+__device__ __forceinline__ int col_dir(int c) { return c < 0 ? 0 : ((c & 1) ? 1 : -1); }
+__device__ __forceinline__ int col_enc(int rail, int dir) { return dir == 0 ? -1 : rail * 2 + (dir > 0 ? 1 : 0); }
+
+// np.argmax(row[from:] == 0) for the row `rail` of a plane given by its columns
+__device__ __forceinline__ int first_zero_col(const int16_t* row, int rail, int from, int T1) {
+  for (int t = from; t < T1; t++)
+    if (!on_rail(row[t], rail)) return t - from;
+  return 0;
+}
+
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+
+struct ColEnv {
+  int16_t* cols;            // [A][T1]
+  int A, T1;
+  const int32_t* status;    // [A]
+  const int32_t* tpc;       // [A]
+  const int32_t* pos;       // [A] cell on the grid, -1 = not on the grid
+  __device__ __forceinline__ int16_t* row(int a) const { return cols + (size_t)a * T1; }
+};
+
+// src/rail_observations.py:161-164
+__device__ __forceinline__ int rail_dir(const ColEnv& m, int a, int ts, int* dir) {
+  const int c = m.row(a)[ts];
+  *dir = col_dir(c);
+  return c < 0 ? 0 : (c >> 1);
+}
+
+// src/rail_observations.py:257-299: the train (other than a, already departed) that leaves `rail` last and its
+// expected exit time (0 = nobody).  Ties keep the lowest agent number.
+__device__ int wave_last_train(const ColEnv& m, int a, int rail, int* last) {
+  const int lane = threadIdx.x;
+  int key = 0;
+  for (int o = lane; o < m.A; o += 64) {
+    if (o == a || m.status[o] == 0) continue;
+    const int16_t* row = m.row(o);
+    const int t = m.tpc[o];
+    int ex = -1;
+    if (on_rail(row[0], rail)) {
+      ex = first_zero_col(row, rail, 0, m.T1);
+    } else if (t >= 1 && t - 1 < m.T1 && on_rail(row[t - 1], rail)) {
+      const int c0 = row[0];
+      const int orail = c0 < 0 ? 0 : (c0 >> 1);
+      ex = 0;
+      if (orail != rail) ex = first_zero_col(row, orail, 0, m.T1);
+      ex += first_zero_col(row, rail, ex, m.T1);
+    }
+    if (ex > 0) key = max(key, (ex << 12) | (4095 - o));
+  }
+  key = wave_max(key);
+  if (key == 0) {
+    *last = 0;
+    return 0;
+  }
+  *last = 4095 - (key & 4095);
+  return key >> 12;
+}
+
+// src/rail_observations.py:192-204
+__device__ bool wave_headon_crash(const ColEnv& m, int a, int rail, int dir) {
+  int last;
+  const int le = wave_last_train(m, a, rail, &last);
+  if (le > 0) {
+    // (an exit time past the horizon would be an IndexError in the reference: read it as an empty column)
+    const int c = le - 1 < m.T1 ? m.row(last)[le - 1] : -1;
+    const int last_dir = on_rail(c, rail) ? col_dir(c) : 0;
+    return last_dir != dir;
+  }
+  return false;
+}
+
+// src/rail_observations.py:182-190
+__device__ bool wave_cell_occupied(const ColEnv& m, int a, int cell) {
+  bool hit = false;
+  for (int o = threadIdx.x; o < m.A; o += 64)
+    if (o != a && m.pos[o] == cell) hit = true;
+  return __ballot(hit) != 0;
+}
+
+// src/rail_observations.py:206-230.  next_cell: the cell the agent's path enters next (-1 = empty path).
+__device__ bool wave_check_crash(const ColEnv& m, int a, bool before_switch, int init_cell, int next_cell) {
+  if (m.status[a] == 0) {
+    if (wave_cell_occupied(m, a, init_cell)) return true;
+    int dir;
+    const int rail = rail_dir(m, a, 1, &dir);
+    return wave_headon_crash(m, a, rail, dir);
+  }
+  if (before_switch) {
+    int t = m.tpc[a];
+    if (t >= m.T1) t = m.T1 - 1;
+    int dir;
+    const int rail = rail_dir(m, a, t, &dir);
+    return wave_headon_crash(m, a, rail, dir);
+  }
+  if (next_cell >= 0) return wave_cell_occupied(m, a, next_cell);
+  return false;
+}
+
+// src/rail_observations.py:167-180
+__device__ void wave_delay(const ColEnv& m, int a, int rail, int dir, int delay) {
+  const int lane = threadIdx.x;
+  int16_t* row = m.row(a);
+  int odir;
+  const int orail = rail_dir(m, a, 0, &odir);
+  const int t = m.tpc[a];
+  int z = delay + t;
+  if (z > m.T1) z = m.T1;
+  int v[FLM_STEP_KT];
+#pragma unroll
+  for (int k = 0; k < FLM_STEP_KT; k++) {
+    const int c = lane + 64 * k;
+    int nv = -1;
+    if (c < m.T1) {
+      if (c >= z) nv = row[c - delay];
+      else if (c < t) nv = col_enc(orail, odir);
+      else nv = col_enc(rail, dir);   // t <= c < t + delay
+    }
+    v[k] = nv;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < FLM_STEP_KT; k++) {
+    const int c = lane + 64 * k;
+    if (c < m.T1) row[c] = (int16_t)v[k];
+  }
+  __syncthreads();
+}
+
+// src/rail_observations.py:232-252
+__device__ void wave_update_bitmaps(const ColEnv& m, int a, bool before_switch) {
+  const int lane = threadIdx.x;
+  int16_t* row = m.row(a);
+  if (before_switch) {
+    int t = m.tpc[a];
+    if (t >= m.T1) t = m.T1 - 1;
+    int dir, last;
+    const int rail = rail_dir(m, a, t, &dir);
+    const int le = wave_last_train(m, a, rail, &last);
+    if (le > 0) {
+      const int cur = first_zero_col(row, rail, t, m.T1) + t;
+      if (cur <= le) wave_delay(m, a, rail, dir, le + t - cur);
+    }
+  }
+  int v[FLM_STEP_KT];
+#pragma unroll
+  for (int k = 0; k < FLM_STEP_KT; k++) {
+    const int c = lane + 64 * k;
+    v[k] = (c + 1 < m.T1) ? row[c + 1] : -1;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < FLM_STEP_KT; k++) {
+    const int c = lane + 64 * k;
+    if (c < m.T1) row[c] = (int16_t)v[k];
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ int path_next_cell(const int32_t* pc, const uint32_t* pm, int head, int len, int W) {
+  if (len < 0 || head >= len) return -1;
+  const int cell = pc[head];
+  const unsigned meta = pm[head];
+  const int act = (meta >> 8) & 0xFF, nh = (meta >> 16) & 3;
+  return act == 4 ? cell : cell + dr(nh) * W + dc(nh);
+}
+
+// Which of the five cases of the training loop (src/main.py:146-249) each agent is in this step:
+// 0 done, 1 ready to depart, 2 before a switch with an action required, 3 action required, 4 otherwise.
+// before_switch follows src/rail_observations.py:142-159 (an exhausted or missing path counts as "before a switch").
+__global__ void rollout_classify_kernel(const int32_t* __restrict__ status, const int32_t* __restrict__ pos_cell,
+                                        const int32_t* __restrict__ action_required,
+                                        const int32_t* __restrict__ path_cell, const uint32_t* __restrict__ path_meta,
+                                        const int32_t* __restrict__ path_head, const int32_t* __restrict__ path_len,
+                                        const int32_t* __restrict__ cell_rail, int n, int A, int H, int W, int Lp,
+                                        int32_t* __restrict__ branch, int32_t* __restrict__ before_switch) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const int e = g / A;
+  const int st = status[g];
+  int bsw = 0;
+  if (st == 1) {
+    const int head = path_head[g], len = path_len[g];
+    if (len >= 0 && head < len) {
+      const int32_t* cr = cell_rail + (size_t)e * H * W;
+      const int pos = pos_cell[g];
+      const int cell = path_cell[(size_t)g * Lp + head];
+      const unsigned meta = path_meta[(size_t)g * Lp + head];
+      const int act = (meta >> 8) & 0xFF, nh = (meta >> 16) & 3;
+      int next_rail = -1;
+      if (act == 4) {
+        next_rail = cr[cell];
+      } else {
+        const int r = cell / W + dr(nh), c = cell % W + dc(nh);
+        if (r >= 0 && r < H && c >= 0 && c < W) next_rail = cr[r * W + c];
+      }
+      const int cur_rail = (pos >= 0 && pos < H * W) ? cr[pos] : -1;
+      bsw = (cur_rail != -1 && next_rail == -1) ? 1 : 0;
+    } else {
+      bsw = 1;
+    }
+  }
+  int b;
+  if (st >= 2) b = 0;
+  else if (st == 0) b = 1;
+  else if (bsw && action_required[g]) b = 2;
+  else if (action_required[g]) b = 3;
+  else b = 4;
+  branch[g] = b;
+  before_switch[g] = bsw;
+}
+
+// The per-agent part of one training-loop step (src/main.py:146-249) for every environment: one wave per
+// environment, agents in handle order.  net_in is the stop/go decision (1 = go) of the agents in cases 1
+// and 2; alt_slot/best pick the alternative a case-2 agent commits to.
+__global__ __launch_bounds__(64) void rollout_apply_kernel(
+    int16_t* __restrict__ cols_all, const int32_t* __restrict__ status_all, const int32_t* __restrict__ tpc_all,
+    const int32_t* __restrict__ pos_all, const int32_t* __restrict__ init_all, const int32_t* __restrict__ branch_all,
+    const int32_t* __restrict__ net_in, const int32_t* __restrict__ alt_slot, const int32_t* __restrict__ best_all,
+    const int32_t* __restrict__ alt_count, const int32_t* __restrict__ alt_len, const int32_t* __restrict__ alt_cell,
+    const uint32_t* __restrict__ alt_meta, const int16_t* __restrict__ alt_cols, int32_t* __restrict__ path_cell,
+    uint32_t* __restrict__ path_meta, int32_t* __restrict__ path_head, int32_t* __restrict__ path_len, int A, int W,
+    int T1, int Lp, int cap_alt, int32_t* __restrict__ action_out, int32_t* __restrict__ crash_out,
+    int32_t* __restrict__ net_out) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  // the environment's columns (A*T1*2 bytes) stay in global memory: they are L2-resident for the whole walk
+  ColEnv m{cols_all + (size_t)e * A * T1, A, T1, status_all + (size_t)e * A, tpc_all + (size_t)e * A,
+           pos_all + (size_t)e * A};
+  for (int a = 0; a < A; a++) {
+    const size_t g = (size_t)e * A + a;
+    const int br = branch_all[g];
+    int net = net_in[g], action = 0, crash = 0;
+    int32_t* pc = path_cell + g * Lp;
+    uint32_t* pm = path_meta + g * Lp;
+    if (br == 0) {
+      for (int c = lane; c < T1; c += 64) m.row(a)[c] = -1;
+      __syncthreads();
+      net = 0;
+    } else if (br == 1) {
+      if (net != 0) {
+        crash = wave_check_crash(m, a, false, init_all[g], -1) ? 1 : 0;
+        if (crash) {
+          net = 0;
+          action = 4;
+        } else {
+          wave_update_bitmaps(m, a, false);
+          action = 2;   // a departing agent moves forward (src/rail_observations.py:117-118)
+        }
+      }
+    } else if (br == 2) {
+      const int slot = alt_slot[g];
+      const int n_alt = slot >= 0 ? alt_count[slot] : 0;
+      if (n_alt > 0) {
+        int b = best_all[g];
+        if (b < 0 || b >= n_alt) b = 0;
+        const size_t q = (size_t)slot * cap_alt + b;
+        const int len = alt_len[q];
+        for (int c = lane; c < T1; c += 64) m.row(a)[c] = alt_cols[q * T1 + c];
+        for (int i = lane; i < len && i < Lp; i += 64) {
+          pc[i] = alt_cell[q * Lp + i];
+          pm[i] = alt_meta[q * Lp + i];
+        }
+        if (lane == 0) {
+          path_head[g] = 0;
+          path_len[g] = len;
+        }
+        __syncthreads();
+      } else {
+        net = 0;
+      }
+      if (net == 0) {
+        action = 4;
+      } else {
+        crash = wave_check_crash(m, a, true, -1, -1) ? 1 : 0;
+        if (crash) {
+          net = 0;
+          action = 4;
+        } else {
+          const int head = path_head[g], len = path_len[g];
+          if (len < 0 || head >= len) {
+            action = 4;
+          } else {
+            const int act = (pm[head] >> 8) & 0xFF;
+            action = (act >= 1 && act <= 3) ? act : 0;
+            __syncthreads();
+            if (lane == 0) path_head[g] = head + 1;
+          }
+          wave_update_bitmaps(m, a, true);
+        }
+      }
+    } else if (br == 3) {
+      const int head = path_head[g], len = path_len[g];
+      crash = wave_check_crash(m, a, false, -1, path_next_cell(pc, pm, head, len, W)) ? 1 : 0;
+      if (crash) {
+        net = 0;
+        action = 4;
+      } else {
+        net = 1;
+        if (len < 0 || head >= len) {
+          action = 4;
+        } else {
+          const int act = (pm[head] >> 8) & 0xFF;
+          action = (act >= 1 && act <= 3) ? act : 0;
+          __syncthreads();
+          if (lane == 0) path_head[g] = head + 1;
+        }
+        wave_update_bitmaps(m, a, false);
+      }
+    } else {
+      net = 1;
+      wave_update_bitmaps(m, a, false);
+    }
+    if (lane == 0) {
+      action_out[g] = action;
+      crash_out[g] = crash;
+      net_out[g] = net;
+    }
+    __syncthreads();
+  }
+}
+
+// One environment step for every environment (agents in handle order, one wave per environment): a train
+// leaves its start cell on a move action if that cell is free; at a cell boundary the action is
+// interpreted (an impossible left/right falls back to forward, an impossible move stops the train); a
+// moving train advances by `speed` per step and enters the next cell when the fraction reaches 1 and the
+// cell is free; a train that reaches its target leaves the grid.  No malfunctions.
+__global__ __launch_bounds__(64) void env_step_kernel(
+    const uint16_t* __restrict__ grid_all, const int32_t* __restrict__ action_all, const int32_t* __restrict__ init_all,
+    const int32_t* __restrict__ init_dir_all, const int32_t* __restrict__ target_all,
+    const double* __restrict__ speed_all, int32_t* __restrict__ status_all, int32_t* __restrict__ pos_all,
+    int32_t* __restrict__ dir_all, int32_t* __restrict__ moving_all, double* __restrict__ frac_all,
+    int32_t* __restrict__ exit_action_all, int32_t* __restrict__ done_all, int A, int H, int W,
+    double* __restrict__ reward_all, int32_t* __restrict__ action_required, int32_t* __restrict__ all_done) {
+  extern __shared__ int s_pos[];
+  const int e = blockIdx.x, lane = threadIdx.x;
+  const size_t base = (size_t)e * A;
+  const uint16_t* grid = grid_all + (size_t)e * H * W;
+  for (int o = lane; o < A; o += 64) s_pos[o] = pos_all[base + o];
+  __syncthreads();
+  auto cell_free = [&](int cell) {
+    bool hit = false;
+    for (int o = lane; o < A; o += 64) hit |= s_pos[o] == cell;
+    return __ballot(hit) == 0;
+  };
+  // (new cell valid && transition valid), new heading, new cell for a move action from (pos, dir)
+  auto check_action = [&](int pos, int dir, int action, int* nd_out, int* np_out) {
+    const int nib = nibble(grid[pos], dir);
+    const int num = __popc(nib);
+    int nd = dir, tv = -1;
+    if (action == 1) {
+      nd = dir - 1;
+      if (num <= 1) tv = 0;
+    } else if (action == 3) {
+      nd = dir + 1;
+      if (num <= 1) tv = 0;
+    }
+    nd &= 3;
+    if (action == 2 && num == 1) {
+      for (int n = 0; n < 4; n++)
+        if (has_exit(nib, n)) { nd = n; break; }
+      tv = 1;
+    }
+    const int r = pos / W + dr(nd), c = pos % W + dc(nd);
+    const bool inside = r >= 0 && r < H && c >= 0 && c < W;
+    const bool cv = inside && grid[r * W + c] != 0;
+    if (tv < 0) tv = has_exit(nib, nd);
+    *nd_out = nd;
+    *np_out = inside ? r * W + c : -1;
+    return cv && tv != 0;
+  };
+  int n_done = 0;
+  for (int i = 0; i < A; i++) {
+    const size_t g = base + i;
+    int status = status_all[g];
+    double reward = 0.0;
+    const double speed = speed_all[g];
+    if (status >= 2) {
+      n_done += done_all[g] ? 1 : 0;
+      if (lane == 0) {
+        reward_all[g] = 0.0;
+        action_required[g] = 0;
+      }
+      continue;
+    }
+    int action = action_all[g];
+    int pos = s_pos[i], dir = dir_all[g], moving = moving_all[g];
+    double frac = frac_all[g];
+    int exit_action = exit_action_all[g];
+    int done = done_all[g];
+    if (status == 0) {
+      if (action >= 1 && action <= 3 && cell_free(init_all[g])) {
+        status = 1;
+        pos = init_all[g];
+        dir = init_dir_all[g];
+        moving = 1;
+      }
+      reward = -speed;
+    } else {
+      if (fabs(frac) < 1e-9) {
+        if (action == 0 && moving) action = 2;
+        if (action == 4 && moving) moving = 0;
+        if (!moving && action != 0 && action != 4) moving = 1;
+        if (moving) {
+          bool valid = false;
+          if (action != 0 && action != 4) {
+            int nd, np;
+            if (check_action(pos, dir, action, &nd, &np)) {
+              valid = true;
+            } else if (action == 1 || action == 3) {
+              action = 2;
+              valid = check_action(pos, dir, action, &nd, &np);
+            }
+          }
+          if (valid) exit_action = action;
+          else moving = 0;
+        }
+      }
+      if (moving) {
+        frac += speed;
+        if (frac > 1.0 - 1e-9) {
+          int nd, np;
+          if (check_action(pos, dir, exit_action, &nd, &np) && cell_free(np)) {
+            pos = np;
+            dir = nd;
+            frac = 0.0;
+          }
+        }
+        if (pos == target_all[g]) {
+          status = 3;
+          pos = -1;
+          moving = 0;
+          done = 1;
+        }
+      }
+      reward = done ? 0.0 : -speed;
+    }
+    n_done += done ? 1 : 0;
+    __syncthreads();
+    if (lane == 0) {
+      s_pos[i] = pos;
+      status_all[g] = status;
+      pos_all[g] = pos;
+      dir_all[g] = dir;
+      moving_all[g] = moving;
+      frac_all[g] = frac;
+      exit_action_all[g] = exit_action;
+      done_all[g] = done;
+      reward_all[g] = reward;
+      action_required[g] = (status == 0 || (status == 1 && fabs(frac) < 1e-9)) ? 1 : 0;
+    }
+    __syncthreads();
+  }
+  if (lane == 0) all_done[e] = n_done == A ? 1 : 0;
+}
+
+}  // namespace flm
+
+extern "C" int flm_rollout_classify(const int32_t* status, const int32_t* pos_cell, const int32_t* action_required,
+                                    const int32_t* path_cell, const uint32_t* path_meta, const int32_t* path_head,
+                                    const int32_t* path_len, const int32_t* cell_rail, int E, int A, int H, int W, int Lp,
+                                    int32_t* branch, int32_t* before_switch, void* stream) {
+  if (!status || !pos_cell || !action_required || !path_cell || !path_meta || !path_head || !path_len || !cell_rail ||
+      !branch || !before_switch)
+    return FLM_E_ARG;
+  if (E <= 0 || A <= 0 || H <= 0 || W <= 0 || Lp <= 0 || (long long)E * A > 0x7FFFFFFF) return FLM_E_ARG;
+  const int n = E * A;
+  hipLaunchKernelGGL(flm::rollout_classify_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, status,
+                     pos_cell, action_required, path_cell, path_meta, path_head, path_len, cell_rail, n, A, H, W, Lp,
+                     branch, before_switch);
+  FLM_CHECK_LAUNCH();
+  return FLM_OK;
+}
+
+extern "C" int flm_rollout_apply(int16_t* cols, const int32_t* status, const int32_t* tpc, const int32_t* pos_cell,
+                                 const int32_t* init_cell, const int32_t* branch, const int32_t* net_in,
+                                 const int32_t* alt_slot, const int32_t* best, const int32_t* alt_count,
+                                 const int32_t* alt_len, const int32_t* alt_cell, const uint32_t* alt_meta,
+                                 const int16_t* alt_cols, int32_t* path_cell, uint32_t* path_meta, int32_t* path_head,
+                                 int32_t* path_len, int E, int A, int W, int T1, int Lp, int cap_alt, int32_t* action,
+                                 int32_t* crash, int32_t* net_out, void* stream) {
+  if (!cols || !status || !tpc || !pos_cell || !init_cell || !branch || !net_in || !alt_slot || !best || !path_cell ||
+      !path_meta || !path_head || !path_len || !action || !crash || !net_out)
+    return FLM_E_ARG;
+  if (E <= 0 || A <= 0 || A > 4095 || W <= 0 || T1 <= 1 || T1 > 64 * FLM_STEP_KT || Lp <= 0 || cap_alt <= 0)
+    return FLM_E_ARG;
+  hipLaunchKernelGGL(flm::rollout_apply_kernel, dim3(E), dim3(64), 0, (hipStream_t)stream, cols, status, tpc, pos_cell,
+                     init_cell, branch, net_in, alt_slot, best, alt_count, alt_len, alt_cell, alt_meta, alt_cols,
+                     path_cell, path_meta, path_head, path_len, A, W, T1, Lp, cap_alt, action, crash, net_out);
+  FLM_CHECK_LAUNCH();
+  return FLM_OK;
+}
+
+extern "C" int flm_env_step(const uint16_t* grid, const int32_t* action, const int32_t* init_cell,
+                            const int32_t* init_dir, const int32_t* target_cell, const double* speed, int32_t* status,
+                            int32_t* pos_cell, int32_t* direction, int32_t* moving, double* fraction,
+                            int32_t* exit_action, int32_t* done, int E, int A, int H, int W, double* reward,
+                            int32_t* action_required, int32_t* all_done, void* stream) {
+  if (!grid || !action || !init_cell || !init_dir || !target_cell || !speed || !status || !pos_cell || !direction ||
+      !moving || !fraction || !exit_action || !done || !reward || !action_required || !all_done)
+    return FLM_E_ARG;
+  if (E <= 0 || A <= 0 || A > 8192 || H <= 0 || W <= 0) return FLM_E_ARG;
+  hipLaunchKernelGGL(flm::env_step_kernel, dim3(E), dim3(64), sizeof(int) * (size_t)A, (hipStream_t)stream, grid, action,
+                     init_cell, init_dir, target_cell, speed, status, pos_cell, direction, moving, fraction, exit_action,
+                     done, A, H, W, reward, action_required, all_done);
+  FLM_CHECK_LAUNCH();
+  return FLM_OK;
+}

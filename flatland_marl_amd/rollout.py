@@ -1,0 +1,231 @@
+"""Batched rollout: the per-step loop of the reference's training script (src/main.py:142-252) for E
+environments at once, state resident on the GPU.
+
+The occupancy planes live in column form ([E,A,T1] int16, see ObservationBatch.columns): every rule of the
+loop (shift, delay, crash checks) moves or reads whole columns.  One step is
+
+    classify   -> which of the five cases of src/main.py:146-249 each agent is in
+    altpaths   -> alternatives (paths + planes) of the agents in front of a switch
+    policy     -> stop/go and the chosen alternative (the network of src/main.py:168-172, 197-208, or any
+                  other callable; it may ask for the observations of the consulting agents)
+    apply      -> the sequential per-agent bookkeeping, one wave per environment
+    env step   -> the environment advances (stand-in for flatland's RailEnv.step, no malfunctions)
+
+Dense observations are only produced for the agents that consult the policy.
+"""
+import numpy as np
+import torch
+
+from ._lib import call, ptr
+from .batch import ObservationBatch
+
+MAX_REQ = 65535      # requests per launch of the request kernels
+
+
+class RolloutBatch:
+    def __init__(self, batch: ObservationBatch, speed, initial_direction=None, cap_alt=4, max_alt_depth=500):
+        self.b = b = batch
+        E, A, dev = b.E, b.A, b.device
+        self.E, self.A, self.device = E, A, dev
+        self.cap_alt = int(cap_alt)
+        self.max_alt_depth = int(max_alt_depth)
+        self.Lp = self.max_alt_depth + 40
+        self.speed = torch.as_tensor(np.asarray(speed, np.float64).reshape(E, A), device=dev)
+        self.init_dir = b.direction.clone() if initial_direction is None else \
+            torch.as_tensor(np.asarray(initial_direction, np.int32).reshape(E, A), device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.status = torch.zeros((E, A), **i32)
+        self.pos = torch.full((E, A), -1, **i32)             # cell on the grid, -1 = not on the grid
+        self.heading = self.init_dir.clone()
+        self.moving = torch.zeros((E, A), **i32)
+        self.fraction = torch.zeros((E, A), dtype=torch.float64, device=dev)
+        self.exit_action = torch.zeros((E, A), **i32)
+        self.done = torch.zeros((E, A), **i32)
+        self.all_done = torch.zeros((E,), **i32)
+        self.reward = torch.zeros((E, A), dtype=torch.float64, device=dev)
+        self.action_required = torch.ones((E, A), **i32)
+        self.path_cell = torch.zeros((E, A, self.Lp), **i32)
+        self.path_meta = torch.zeros((E, A, self.Lp), **i32)
+        self.path_head = torch.zeros((E, A), **i32)
+        self.path_len = torch.zeros((E, A), **i32)
+        self.branch = torch.zeros((E, A), **i32)
+        self.before_switch = torch.zeros((E, A), **i32)
+        self.action = torch.zeros((E, A), **i32)
+        self.crash = torch.zeros((E, A), **i32)
+        self.net = torch.zeros((E, A), **i32)
+        self.alt_slot = torch.full((E, A), -1, **i32)
+        self.agent_err = torch.zeros((E, A), **i32)          # sticky: first error code seen for the agent
+        self._dummy_i32 = torch.zeros((1,), **i32)
+        self._dummy_i16 = torch.zeros((1,), dtype=torch.int16, device=dev)
+        self.cols = None
+        self.t = 0
+
+    @property
+    def stream(self):
+        return self.b.stream.cuda_stream
+
+    # ------------------------------------------------------------------ reset
+    def reset(self):
+        """env.reset(): every agent ready to depart, shortest paths and planes of all agents (get_many)."""
+        b = self.b
+        self.status.zero_()
+        self.pos.fill_(-1)
+        self.heading.copy_(self.init_dir)
+        self.moving.zero_()
+        self.fraction.zero_()
+        self.exit_action.zero_()
+        self.done.zero_()
+        self.all_done.zero_()
+        self.action_required.fill_(1)
+        self.agent_err.zero_()
+        b.status.zero_()
+        b.pos_cell.copy_(b.start_cell)
+        b.direction.copy_(self.init_dir)
+        if b.R is None:
+            b.build_graph(sync=True)
+        if getattr(b, "dist", None) is None:
+            b.compute_distances()
+        b.shortest_paths()
+        self.cols = b.columns(shift=1)
+        n = min(b.Lcap, self.Lp)
+        self.path_cell[:, :, :n] = b.path_cell[:, :, :n]
+        self.path_meta[:, :, :n] = b.path_meta[:, :, :n]
+        self.path_len.copy_(b.path_len)
+        self.path_head.zero_()
+        self.agent_err.copy_(b.agent_err)
+        self.t = 0
+        return self
+
+    # ------------------------------------------------------------------ pieces of a step
+    def classify(self):
+        b = self.b
+        call("flm_rollout_classify", ptr(self.status), ptr(self.pos), ptr(self.action_required), ptr(self.path_cell),
+             ptr(self.path_meta), ptr(self.path_head), ptr(self.path_len), ptr(b.cell_rail), self.E, self.A, b.H, b.W,
+             self.Lp, ptr(self.branch), ptr(self.before_switch), self.stream)
+        return self.branch
+
+    def alternatives(self, req):
+        """Alternative paths and their planes (column form) for the agents req[n] (flat e*A+a, all ACTIVE):
+        get_altmaps, src/rail_observations.py:97-111."""
+        b = self.b
+        n, K, dev = req.numel(), self.cap_alt, self.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        # the path kernels read the agents' current cell and heading from the batch
+        b.pos_cell.copy_(torch.where(self.pos >= 0, self.pos, b.start_cell))
+        b.direction.copy_(self.heading)
+        b.status.copy_(self.status)
+        alt = dict(count=torch.empty((n,), **i32), len=torch.zeros((n, K), **i32),
+                   cell=torch.empty((n, K, self.Lp), **i32), meta=torch.empty((n, K, self.Lp), **i32),
+                   err=torch.empty((n,), **i32), cols=torch.empty((n, K, b.T1), dtype=torch.int16, device=dev),
+                   col_err=torch.empty((n, K), **i32), req=req)
+        for lo in range(0, n, MAX_REQ):
+            hi = min(n, lo + MAX_REQ)
+            call("flm_altpaths", ptr(b.grid), ptr(b.cell_idx), ptr(b.dist), ptr(b.tslot), ptr(b.node_id), ptr(req[lo:hi]),
+                 hi - lo, ptr(b.pos_cell), ptr(b.direction), ptr(b.target_cell), self.E, self.A, b.H, b.W, b.cap_cells,
+                 self.max_alt_depth, K, self.Lp, ptr(alt["count"][lo:hi]), ptr(alt["len"][lo:hi]), ptr(alt["cell"][lo:hi]),
+                 ptr(alt["meta"][lo:hi]), ptr(alt["err"][lo:hi]), self.stream)
+        agent_flat = req.repeat_interleave(K).contiguous()
+        call("flm_columns", ptr(alt["cell"]), ptr(alt["len"]), ptr(agent_flat), ptr(b.pos_cell), ptr(b.target_cell),
+             ptr(b.tpc), ptr(b.node_id), ptr(b.cell_rail), ptr(b.edge_info), self.E, self.A, n * K, b.H, b.W, b.capR,
+             b.Rp, b.T1, self.Lp, 0, ptr(alt["cols"]), ptr(alt["col_err"]), self.stream)
+        # an alternative whose path cannot be mapped on the rail graph raises in the reference; here the agent
+        # is flagged and treated as having no alternatives
+        used = torch.arange(K, device=dev)[None, :] < alt["count"][:, None]
+        bad = ((alt["col_err"] != 0) & used).any(dim=1) | (alt["err"] != 0)
+        first = torch.where(alt["err"] != 0, alt["err"], (alt["col_err"] * used).max(dim=1).values)
+        flat_err = self.agent_err.view(-1)
+        flat_err[req.long()] = torch.where(flat_err[req.long()] != 0, flat_err[req.long()], first.to(torch.int32))
+        alt["count"] = torch.where(bad, torch.zeros_like(alt["count"]), alt["count"])
+        return alt
+
+    def consult_observations(self, req, own_cols=None, out=None):
+        """[n,3,plane_stride] uint8 observations of the agents req[n] against the current planes
+        (get_obs, src/preprocessing.py:61-74); own_cols [n,T1] replaces the planes shown as their own."""
+        b = self.b
+        n = req.numel()
+        if out is None:
+            out = torch.empty((n, 3, b.plane_stride), dtype=torch.uint8, device=self.device)
+        for lo in range(0, n, MAX_REQ):
+            hi = min(n, lo + MAX_REQ)
+            call("flm_observations_req_columns", ptr(self.cols), ptr(req[lo:hi]),
+                 ptr(own_cols[lo:hi]) if own_cols is not None else None, hi - lo, self.E, self.A, b.Rp, b.T1,
+                 b.plane_stride, ptr(out[lo:hi]), self.stream)
+        return out
+
+    def apply(self, net_in, best, alt):
+        b = self.b
+        a = alt if alt is not None else dict(count=self._dummy_i32, len=self._dummy_i32, cell=self._dummy_i32,
+                                             meta=self._dummy_i32, cols=self._dummy_i16)
+        call("flm_rollout_apply", ptr(self.cols), ptr(self.status), ptr(b.tpc), ptr(self.pos), ptr(b.start_cell),
+             ptr(self.branch), ptr(net_in), ptr(self.alt_slot), ptr(best), ptr(a["count"]), ptr(a["len"]),
+             ptr(a["cell"]), ptr(a["meta"]), ptr(a["cols"]), ptr(self.path_cell), ptr(self.path_meta),
+             ptr(self.path_head), ptr(self.path_len), self.E, self.A, b.W, b.T1, self.Lp, self.cap_alt,
+             ptr(self.action), ptr(self.crash), ptr(self.net), self.stream)
+
+    def env_step(self):
+        b = self.b
+        call("flm_env_step", ptr(b.grid), ptr(self.action), ptr(b.start_cell), ptr(self.init_dir), ptr(b.target_cell),
+             ptr(self.speed), ptr(self.status), ptr(self.pos), ptr(self.heading), ptr(self.moving), ptr(self.fraction),
+             ptr(self.exit_action), ptr(self.done), self.E, self.A, b.H, b.W, ptr(self.reward),
+             ptr(self.action_required), ptr(self.all_done), self.stream)
+
+    # ------------------------------------------------------------------ one step
+    def step(self, policy):
+        """One pass of src/main.py:142-252 over every environment.
+
+        policy(rollout, info) -> (net [E,A] int32: 1 = go, best [E,A] int32: chosen alternative).  info holds
+        branch [E,A], req_ready (flat indices of the agents about to depart), req_switch (agents before a
+        switch), alt (their alternatives: count, len, cell, meta, cols) and t (the step number).  The policy
+        sees the planes as they were when the step began (src/main.py:144)."""
+        self.classify()
+        flat = self.branch.view(-1)
+        req_switch = torch.nonzero(flat == 2).view(-1).to(torch.int32)
+        req_ready = torch.nonzero(flat == 1).view(-1).to(torch.int32)
+        self.alt_slot.fill_(-1)
+        alt = None
+        if req_switch.numel() > 0:
+            alt = self.alternatives(req_switch)
+            self.alt_slot.view(-1)[req_switch.long()] = torch.arange(req_switch.numel(), dtype=torch.int32,
+                                                                     device=self.device)
+        info = dict(t=self.t, branch=self.branch, req_ready=req_ready, req_switch=req_switch, alt=alt)
+        net_in, best = policy(self, info)
+        self.apply(net_in, best, alt)
+        self.env_step()
+        self.t += 1
+        info["net_in"], info["best"] = net_in, best
+        return info
+
+    # ------------------------------------------------------------------ host views (tests)
+    def maps_numpy(self, e=0, R=None):
+        """Dense [A,R,T1] int8 planes of one environment, rebuilt from the columns."""
+        b = self.b
+        R = int(b.R[e]) if R is None else R
+        cols = self.cols[e].cpu().numpy().astype(np.int64)
+        out = np.zeros((self.A, R, b.T1), np.int8)
+        a, t = np.nonzero(cols >= 0)
+        c = cols[a, t]
+        out[a, c >> 1, t] = np.where(c & 1, 1, -1)
+        return out
+
+
+def hash_policy(rollout, info):
+    """Deterministic stand-in for the network (tests): go 7 times out of 8, alternative = hash % n_alt;
+    the same function of (step, agent) for every environment."""
+    A, dev = rollout.A, rollout.device
+    net = np.zeros(A, np.int32)
+    sel = np.zeros(A, np.int64)
+    for a in range(A):
+        x = (info["t"] * 7919 + a * 104729 + 12345) & 0x7FFFFFFF
+        x = (x * 1103515245 + 12345) & 0x7FFFFFFF
+        x = (x * 1103515245 + 12345) & 0x7FFFFFFF
+        net[a] = 1 if ((x >> 16) % 8) != 0 else 0
+        sel[a] = (x >> 8) & 0xFFFF
+    net_in = torch.as_tensor(net, device=dev)[None, :].expand(rollout.E, A).contiguous()
+    best = torch.zeros((rollout.E, A), dtype=torch.int32, device=dev)
+    alt = info["alt"]
+    if alt is not None:
+        req = info["req_switch"].long()
+        n_alt = alt["count"].long()
+        s = torch.as_tensor(sel, device=dev)[req % A]
+        best.view(-1)[req] = torch.where(n_alt > 0, s % torch.clamp(n_alt, min=1), torch.zeros_like(s)).to(torch.int32)
+    return net_in, best

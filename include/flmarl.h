@@ -170,6 +170,12 @@ int flm_observations_columns(const int16_t* cols, int E, int A, int Rp, int T1, 
 int flm_observations_req(const int8_t* maps, const int32_t* req_agent, const int8_t* own_planes, int n_req, int E,
                          int A, int plane_stride, uint8_t* out, void* stream);
 
+/* flm_observations_req on the column form (see flm_columns): cols [E,A,T1] int16 are the agents' planes,
+ * own_cols [n_req,T1] int16 or NULL the planes shown as their own.  Same output as flm_observations_req for
+ * the planes those columns describe. */
+int flm_observations_req_columns(const int16_t* cols, const int32_t* req_agent, const int16_t* own_cols, int n_req,
+                                 int E, int A, int Rp, int T1, int plane_stride, uint8_t* out, void* stream);
+
 /* Rail reordering of finished observations.
  * Replaces ObsPreprocessor._reorder_rails / _swap_rails, src/preprocessing.py:32-59 (enabled by
  * --reorder-rails, src/main.py:395): the rails the own plane (plane 0) visits, in order of first visit,
@@ -213,6 +219,46 @@ int flm_check_crash(const int8_t* maps, const int32_t* status, const int32_t* tp
  * maps is updated in place. */
 int flm_update_bitmaps(int8_t* maps, const int32_t* status, const int32_t* tpc, const int32_t* agent_sel,
                        const int32_t* before_switch, int E, int A, int Rp, int T1, int plane_stride, void* stream);
+
+/* ---- Batched rollout step on the column form of the planes (cols [E,A,T1] int16, see flm_columns) ----
+ * Paths are [E,A,Lp] arrays in the encoding of flm_shortest_paths with a read position path_head [E,A]
+ * and a length path_len [E,A] (-1 = None): the list paths[a] of the reference is elements head..len-1.
+ *
+ * flm_rollout_classify: which case of the training loop (src/main.py:146-249) every agent is in:
+ *   branch [E,A] out: 0 done (:147), 1 ready to depart (:160), 2 before a switch with an action required
+ *   (:187), 3 action required (:232), 4 otherwise (:243); before_switch [E,A] out follows is_before_switch,
+ *   src/rail_observations.py:142-159.  status/pos_cell/action_required [E,A]; cell_rail of flm_graph_build. */
+int flm_rollout_classify(const int32_t* status, const int32_t* pos_cell, const int32_t* action_required,
+                         const int32_t* path_cell, const uint32_t* path_meta, const int32_t* path_head,
+                         const int32_t* path_len, const int32_t* cell_rail, int E, int A, int H, int W, int Lp,
+                         int32_t* branch, int32_t* before_switch, void* stream);
+
+/* flm_rollout_apply: the per-agent part of one step of the training loop for every environment, agents
+ * in handle order (src/main.py:146-249 with check_crash, update_bitmaps, _delay, get_agent_action and
+ * set_agent_path, src/rail_observations.py:113-140, 161-299), given the stop/go decisions:
+ *   net_in [E,A]: 1 = go, for the agents of cases 1 and 2 (the network's choice, src/main.py:168-172, 202-208);
+ *   alt_slot [E,A]: row of the alt_* tables that holds the agent's alternatives (-1 = none), best [E,A] the
+ *   alternative it commits to; alt_count [n], alt_len [n,cap_alt], alt_cell/alt_meta [n,cap_alt,Lp] as
+ *   written by flm_altpaths, alt_cols [n,cap_alt,T1] their planes in column form (flm_columns);
+ *   cols, path_* are updated in place; action [E,A] out is the RailEnvActions value handed to the
+ *   environment, crash [E,A] out, net_out [E,A] the decision after the crash checks.
+ * T1 <= 512, A <= 4095. */
+int flm_rollout_apply(int16_t* cols, const int32_t* status, const int32_t* tpc, const int32_t* pos_cell,
+                      const int32_t* init_cell, const int32_t* branch, const int32_t* net_in, const int32_t* alt_slot,
+                      const int32_t* best, const int32_t* alt_count, const int32_t* alt_len, const int32_t* alt_cell,
+                      const uint32_t* alt_meta, const int16_t* alt_cols, int32_t* path_cell, uint32_t* path_meta,
+                      int32_t* path_head, int32_t* path_len, int E, int A, int W, int T1, int Lp, int cap_alt,
+                      int32_t* action, int32_t* crash, int32_t* net_out, void* stream);
+
+/* flm_env_step: one environment step for every environment, agents in handle order.  Stands in for
+ * flatland RailEnv.step as called at src/main.py:252 (third-party, absent: restated from its published
+ * rules without malfunctions; the same rules as the stand-in the golden traces were recorded with).
+ *   status/pos_cell/direction/moving/fraction/exit_action/done [E,A] are updated in place (fraction,
+ *   speed, reward are double); reward [E,A], action_required [E,A], all_done [E] out. */
+int flm_env_step(const uint16_t* grid, const int32_t* action, const int32_t* init_cell, const int32_t* init_dir,
+                 const int32_t* target_cell, const double* speed, int32_t* status, int32_t* pos_cell,
+                 int32_t* direction, int32_t* moving, double* fraction, int32_t* exit_action, int32_t* done, int E,
+                 int A, int H, int W, double* reward, int32_t* action_required, int32_t* all_done, void* stream);
 
 /* ---- Dueling Double-DQN (fp32; matrix products on the fp32 MFMA) -------------------------------------
  * Replaces Dueling_DQN.forward, src/model.py:31-43, and the numeric part of DQNAgent.act / learn /

@@ -1,0 +1,72 @@
+"""Batched training driver: plumbing between the rollout, the replay memory and the DQN kernels (needs an MI355X)."""
+import types
+
+import numpy as np
+import pytest
+
+from tests.golden_util import load_env
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(E=4, A=10, depth=150, Rp=100, name="Test_0_Level_0", **kw):
+    import torch
+    import flatland_marl_amd as fm
+    from flatland_marl_amd.agent import DQNAgent
+    from flatland_marl_amd.rollout import RolloutBatch
+    from flatland_marl_amd.train import BatchedTrainer
+    fx = load_env(name)
+    rep = lambda x: np.repeat(np.asarray(x)[None, :A], E, axis=0)
+    b = fm.ObservationBatch(np.repeat(fx["grid"][None], E, axis=0), rep(fx["initial_position"]),
+                            rep(fx["initial_direction"]), rep(fx["target"]), rep(fx["speed"]), depth, max_rails=Rp)
+    ro = RolloutBatch(b, rep(fx["speed"]), rep(fx["initial_direction"])).reset()
+    args = types.SimpleNamespace(prediction_depth=depth, lr=5e-5, buffer_size=2000, batch_size=32, update_every=10,
+                                 gamma=0.99, tau=1e-3)
+    torch.manual_seed(0)
+    agent = DQNAgent(args, action_space=2, bitmap_height=3 * Rp)
+    return ro, agent, BatchedTrainer(ro, agent, **kw)
+
+
+def test_policy_q_values_match_act():
+    import torch
+    ro, agent, tr = _setup()
+    b = ro.b
+    ro.classify()
+    req = torch.nonzero(ro.branch.view(-1) == 1).view(-1).to(torch.int32)
+    assert req.numel() == ro.E * ro.A                       # every agent is ready to depart after reset
+    obs = ro.consult_observations(req)
+    q = tr.policy.q_values(ro, obs).cpu().numpy()
+    o = obs[:, :, :b.Rp * b.T1].cpu().numpy().reshape(-1, 3, b.Rp, b.T1)
+    for k in (0, 7, req.numel() - 1):
+        state = o[k].astype(np.float64)
+        state[0] = o[k, 0].view(np.int8)
+        want = agent.act(state.reshape(3 * b.Rp, b.T1)).cpu().numpy()
+        assert np.allclose(q[k], want, rtol=1e-5, atol=1e-6)
+    # the observation of a request equals the all-agents sweep
+    full = b.observations_fused()
+    assert torch.equal(full.view(-1, 3, b.plane_stride)[req.long()], obs)
+
+
+def test_training_episode_runs_and_learns():
+    import torch
+    ro, agent, tr = _setup(start_eps=0.5, crash_penalty=True, max_learns_per_step=2, max_steps=60)
+    before = agent.qnetwork_local.flat_params().clone()
+    out = tr.run_episode(train=True)
+    torch.cuda.synchronize()
+    assert out["steps"] >= 1 and out["transitions"] > 0 and len(tr.replay) > 0
+    assert out["learns"] > 0
+    assert torch.isfinite(agent.last_loss).all()
+    after = agent.qnetwork_local.flat_params()
+    assert torch.isfinite(after).all() and not torch.equal(before, after)
+    assert int(ro.action.min()) >= 0 and int(ro.action.max()) <= 4
+    st = ro.status.cpu().numpy()
+    assert set(np.unique(st)).issubset({0, 1, 3})
+    assert not ro.agent_err.any()
+    # stored transitions are observations: own plane in {-1,0,1}, rewards <= 0 or the crash penalty
+    n = len(tr.replay)
+    own = tr.replay.state[:n, 0].view(torch.int8)
+    assert int(own.min()) >= -1 and int(own.max()) <= 1
+    r = tr.replay.reward[:n]
+    assert bool(((r <= 0) | (r == -100)).all())
+    out2 = tr.run_episode(train=True)                         # a second episode resets cleanly
+    assert out2["steps"] >= 1 and out2["eps"] < 0.5
