@@ -23,7 +23,7 @@ MAX_REQ = 65535      # requests per launch of the request kernels
 
 
 class RolloutBatch:
-    def __init__(self, batch: ObservationBatch, speed, initial_direction=None, cap_alt=4, max_alt_depth=500):
+    def __init__(self, batch: ObservationBatch, speed, initial_direction=None, cap_alt=8, max_alt_depth=500):
         self.b = b = batch
         E, A, dev = b.E, b.A, b.device
         self.E, self.A, self.device = E, A, dev
