@@ -64,6 +64,44 @@ def cpu_baseline(data, depth, Rp, budget_s=12.0, max_envs=64):
                        "C restatement of the reference algorithm (oracle/flmarl_oracle.c)" % (n_env, n_obs, dt))
 
 
+def rollout_sample(device, steps=40):
+    """Environment steps per second of the batched rollout (src/main.py:142-299 for every environment at once)
+    on the 1024 x 10 workload with max_rails = 100 (the reference's setting, src/main.py:91): the network
+    consulted by every departing agent and every agent in front of a switch, first without, then with
+    learning (one learn step per 10 stored transitions, at most 4 per rollout step)."""
+    import types
+    import flatland_marl_amd as fm
+    from flatland_marl_amd.agent import DQNAgent
+    from flatland_marl_amd.rollout import RolloutBatch
+    from flatland_marl_amd.synthetic import make_batch
+    from flatland_marl_amd.train import BatchedTrainer
+    names, E, A, depth, desc = WORKLOADS["cfg2"]
+    data = make_batch(load_fixtures(names), E, A, seed=0)
+    b = fm.ObservationBatch(data["grid"], data["start"], data["direction"], data["target"], data["speed"], depth,
+                            max_rails=100, device=device)
+    ro = RolloutBatch(b, data["speed"], data["direction"]).reset()
+    a = types.SimpleNamespace(prediction_depth=depth, lr=5e-5, buffer_size=20000, batch_size=512, update_every=10,
+                              gamma=0.99, tau=1e-3)
+    agent = DQNAgent(a, action_space=2, bitmap_height=3 * b.Rp)
+    tr = BatchedTrainer(ro, agent, start_eps=0.1, max_learns_per_step=4)
+    out = {"unit": "env-steps/s", "config": {"workload": "cfg2: " + desc, "envs": E, "agents": A, "rails_padded": int(b.Rp),
+                                             "depth": depth, "steps_timed": steps, "eps": 0.1}}
+    for key, train in (("act_only", False), ("act_and_learn", True)):
+        ro.reset()
+        for _ in range(3):
+            tr.step(train=train)
+        n0, l0 = tr.n_transitions, tr.n_learn
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.step(train=train)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out[key] = {"value": E / dt, "ms_per_step": dt * 1e3, "transitions_per_step": (tr.n_transitions - n0) / steps,
+                    "learn_steps_per_step": (tr.n_learn - l0) / steps}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,6 +116,7 @@ def main():
     ap.add_argument("--obs-serial", type=int, default=1,
                     help="1: observation kernels run one after the other on the main stream after the other stages")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rollout", action="store_true", help="skip the env-steps/s sample of the batched rollout")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -215,6 +254,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data, depth, int(Rp))
+        if world == 1 and not args.no_rollout:
+            out["env_steps"] = rollout_sample(device)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

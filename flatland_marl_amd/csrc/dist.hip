@@ -292,54 +292,77 @@ __global__ __launch_bounds__(FLM_DC_THREADS) void distance_chain_kernel(
       }
     }
     wave_sync();
+    // list sizes live in (wave-uniform) registers; appends are placed by ballot ranks, so the only LDS
+    // atomics left are the dirty-set updates, which rarely meet on one address
+    int n_c = min(cnt[0], FLM_DC_LIST);
     for (int round = 0; round < ((dbg & 1) ? 0 : 65536); round++) {
-      const int nc = min(cnt[0], FLM_DC_LIST);
-      if (nc == 0) {
+      if (n_c == 0) {
         if ((dbg & 16) && tid == 0) counts_all[e * 4 + 2] = round;
         break;
       }
       // phase 1: predecessors of the changed pairs become dirty
-      for (int i = lane; i < nc; i += 64) {
-        const unsigned pr = lc[i];
+      int n_d = 0;
+      for (int base = 0; base < n_c; base += 64) {
+        const int i = base + lane;
+        const bool have = i < n_c;
+        const unsigned pr = have ? lc[i] : 0u;
         const unsigned r = pr & 0x7FFu, bit = 1u << (pr >> 11);
-        for (unsigned q = rev_off[r]; q < rev_off[r + 1]; q++) {
-          const unsigned b = rev_list[q];
-          if (!(atomicOr(&dirty[b], bit) & bit)) {
-            const int pos = atomicAdd(&cnt[1], 1);
-            if (pos < FLM_DC_LIST) ld[pos] = (uint16_t)(b | (pr & 0xF800u));
+        unsigned q = have ? rev_off[r] : 0u;
+        const unsigned qe = have ? rev_off[r + 1] : 0u;
+        while (__ballot(q < qe)) {
+          bool fresh = false;
+          unsigned bb = 0;
+          if (q < qe) {
+            bb = rev_list[q++];
+            fresh = !(atomicOr(&dirty[bb], bit) & bit);
+          }
+          const unsigned long long mk = __ballot(fresh);
+          if (fresh) {
+            const int pos = n_d + __popcll(mk & lanemask_lt());
+            if (pos < FLM_DC_LIST) ld[pos] = (uint16_t)(bb | (pr & 0xF800u));
             else s_lost = 1;
           }
+          n_d += __popcll(mk);
         }
       }
       wave_sync();
-      const int nd = min(cnt[1], FLM_DC_LIST);
-      wave_sync();
-      if (lane == 0) { cnt[0] = 0; cnt[1] = 0; }
-      wave_sync();
+      const int nd = min(n_d, FLM_DC_LIST);
       // phase 2: re-evaluate the dirty pairs; the changed list has been consumed and is refilled
-      for (int i = lane; i < nd; i += 64) {
-        const unsigned pr = ld[i];
-        const unsigned b = pr & 0x7FFu, j = pr >> 11;
-        const uint4 eb = ed[b];
-        const unsigned ev[4] = {eb.x, eb.y, eb.z, eb.w};
-        const unsigned cur = da[b * FLM_DA_ROW + j];
-        unsigned best = cur;
+      n_c = 0;
+      for (int base = 0; base < nd; base += 64) {
+        const int i = base + lane;
+        bool improved = false;
+        unsigned pr = 0;
+        if (i < nd) {
+          pr = ld[i];
+          const unsigned bb = pr & 0x7FFu, j = pr >> 11;
+          const uint4 eb = ed[bb];
+          const unsigned ev[4] = {eb.x, eb.y, eb.z, eb.w};
+          const unsigned cur = da[bb * FLM_DA_ROW + j];
+          unsigned best = cur;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          if (ev[k] == 0xFFFFFFFFu) continue;
-          const unsigned d = da[(ev[k] & 0xFFFFu) * FLM_DA_ROW + j];
-          if (d == FLM_NONE16) continue;
-          const unsigned cand = d + (ev[k] >> 16);
-          if (cand < best) best = cand;
+          for (int k = 0; k < 4; k++) {
+            if (ev[k] == 0xFFFFFFFFu) continue;
+            const unsigned d = da[(ev[k] & 0xFFFFu) * FLM_DA_ROW + j];
+            if (d == FLM_NONE16) continue;
+            const unsigned cand = d + (ev[k] >> 16);
+            if (cand < best) best = cand;
+          }
+          atomicAnd(&dirty[bb], ~(1u << j));
+          if (best < cur) {
+            da[bb * FLM_DA_ROW + j] = (uint16_t)(best > 0xFFFEu ? 0xFFFEu : best);
+            improved = true;
+          }
         }
-        atomicAnd(&dirty[b], ~(1u << j));
-        if (best < cur) {
-          da[b * FLM_DA_ROW + j] = (uint16_t)(best > 0xFFFEu ? 0xFFFEu : best);
-          const int pos = atomicAdd(&cnt[0], 1);
+        const unsigned long long mk = __ballot(improved);
+        if (improved) {
+          const int pos = n_c + __popcll(mk & lanemask_lt());
           if (pos < FLM_DC_LIST) lc[pos] = (uint16_t)pr;
           else s_lost = 1;
         }
+        n_c += __popcll(mk);
       }
+      n_c = min(n_c, FLM_DC_LIST);
       wave_sync();
     }
   }
