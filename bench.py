@@ -111,8 +111,6 @@ def main():
     ap.add_argument("--envs", type=int, default=0, help="environments per GPU (default: the workload's)")
     ap.add_argument("--chunks", type=int, default=1, help="split the batch into this many sub-batches")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the sub-batches are spread over")
-    ap.add_argument("--obs-lds-pad", type=int, default=0, help=argparse.SUPPRESS)
-    ap.add_argument("--obs-tile", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--obs-serial", type=int, default=1,
                     help="1: observation kernels run one after the other on the main stream after the other stages")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -138,12 +136,6 @@ def main():
     # The batch is processed as `chunks` sub-batches spread over `streams` HIP streams, so that the
     # latency-bound kernels of one sub-batch (graph, distances, paths) overlap the bandwidth-bound
     # observation kernel of another.
-    if args.obs_lds_pad:
-        from flatland_marl_amd import _lib
-        _lib.call("flm_dev_set_option", 3, args.obs_lds_pad)
-    if args.obs_tile:
-        from flatland_marl_amd import _lib
-        _lib.call("flm_dev_set_option", 4, args.obs_tile)
     n_chunks = max(1, min(args.chunks, E))
     streams = [torch.cuda.Stream(device=device) for _ in range(max(1, args.streams))] if args.streams > 1 or n_chunks > 1 \
         else [torch.cuda.current_stream(device)]

@@ -8,7 +8,6 @@
 // distance is the level number, written straight to HBM (unreachable states keep the 0xFFFF fill).
 #include "flm_common.h"
 
-extern int g_flm_dev_opt[8];
 
 namespace flm {
 
@@ -132,87 +131,6 @@ __global__ __launch_bounds__(1024) void distance_bfs_kernel(const uint16_t* __re
   }
 }
 
-// Bit-parallel variant: one workgroup runs the BFS of up to 32 distinct targets of one environment
-// together.  Every state carries three 32-bit sets in LDS: visited-by, in-current-frontier-of and
-// in-next-frontier-of (bit j = target slot base+j).  A level sweeps the states; a state with a non-empty
-// frontier set pushes it to its predecessors, and only the bits that were not yet visited there survive
-// (LDS atomic OR returns the previous set, so every (state, target) pair is claimed exactly once and gets
-// distance = level).  The sweep order does not influence the result.
-template <bool PRED_LDS>
-__global__ __launch_bounds__(1024) void distance_bfs_multi_kernel(
-    const uint16_t* __restrict__ pred_all, const int32_t* __restrict__ cell_idx_all,
-    const int32_t* __restrict__ n_cells_all, const int32_t* __restrict__ slot_target,
-    const int32_t* __restrict__ n_slots, int A, int HW, int capCells, uint16_t* __restrict__ dist_all) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int e = blockIdx.y;
-  const int ns = n_slots[e];
-  const int base_slot = blockIdx.x * 32;
-  if (base_slot >= ns) return;
-  const int S = n_cells_all[e] * 4;
-  const int capS = capCells * 4;
-  const int T = blockDim.x, tid = threadIdx.x;
-  unsigned* V = reinterpret_cast<unsigned*>(smem);
-  unsigned* F0 = V + capS;
-  unsigned* F1 = F0 + capS;
-  const uint2* pred_g = reinterpret_cast<const uint2*>(pred_all + (size_t)e * capS * 4);
-  uint2* pred_l = reinterpret_cast<uint2*>(F1 + capS);
-  for (int s = tid; s < S; s += T) {
-    V[s] = 0;
-    F0[s] = 0;
-    F1[s] = 0;
-    if (PRED_LDS) pred_l[s] = pred_g[s];
-  }
-  __syncthreads();
-  uint16_t* dist = dist_all + ((size_t)e * A + base_slot) * capS;
-  if (tid < 32 && base_slot + tid < ns) {
-    const int tcell = slot_target[(size_t)e * A + base_slot + tid];
-    if (tcell >= 0 && tcell < HW) {
-      const int tidx = cell_idx_all[(size_t)e * HW + tcell];
-      if (tidx >= 0) {
-        for (int h = 0; h < 4; h++) {
-          int s = tidx * 4 + h;
-          atomicOr(&V[s], 1u << tid);
-          atomicOr(&F0[s], 1u << tid);
-          dist[(size_t)tid * capS + s] = 0;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  unsigned* cur = F0;
-  unsigned* nxt = F1;
-  for (unsigned level = 1; level < 0xFFFEu; level++) {
-    int any = 0;
-    for (int s = tid; s < S; s += T) {
-      const unsigned f = cur[s];
-      if (!f) continue;
-      cur[s] = 0;
-      any = 1;
-      const uint2 pv = PRED_LDS ? pred_l[s] : pred_g[s];
-      const unsigned p[4] = {pv.x & 0xFFFFu, pv.x >> 16, pv.y & 0xFFFFu, pv.y >> 16};
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        if (p[k] == 0xFFFFu) continue;
-        unsigned nv = f & ~V[p[k]];
-        if (!nv) continue;
-        const unsigned old = atomicOr(&V[p[k]], nv);
-        nv &= ~old;
-        if (!nv) continue;
-        atomicOr(&nxt[p[k]], nv);
-        while (nv) {
-          const int j = __ffs(nv) - 1;
-          nv &= nv - 1;
-          dist[(size_t)j * capS + p[k]] = (uint16_t)level;
-        }
-      }
-    }
-    if (!__syncthreads_or(any)) break;
-    unsigned* t = cur;
-    cur = nxt;
-    nxt = t;
-  }
-}
-
 __global__ void shortest_paths_kernel(const uint16_t* __restrict__ grid_all, const int32_t* __restrict__ cell_idx_all,
                                       const uint16_t* __restrict__ dist_all, const int32_t* __restrict__ tslot,
                                       const int32_t* __restrict__ start_cell, const int32_t* __restrict__ start_dir,
@@ -253,25 +171,6 @@ extern "C" int flm_distance_bfs(const uint16_t* pred, const int32_t* cell_idx, c
   hipLaunchKernelGGL(flm::target_slots_kernel, dim3(E), dim3(256), sizeof(int) * 2 * (size_t)A, stream, target_cell, A,
                      tslot, n_slots, slot_target);
   FLM_CHECK_LAUNCH();
-  const int variant = g_flm_dev_opt[1];  // 0 = one wave per target (default), 1 = bit-parallel, 32 targets per workgroup
-  const size_t masks = capS * 12;
-  if (variant == 1 && masks <= kLdsBudget) {
-    const bool pred_lds = masks + capS * 8 <= kLdsBudget;
-    const size_t lds = masks + (pred_lds ? capS * 8 : 0);
-    dim3 grid((A + 31) / 32, E);
-    const void* fn = pred_lds ? reinterpret_cast<const void*>(flm::distance_bfs_multi_kernel<true>)
-                              : reinterpret_cast<const void*>(flm::distance_bfs_multi_kernel<false>);
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return FLM_E_LAUNCH;
-    if (pred_lds)
-      hipLaunchKernelGGL(flm::distance_bfs_multi_kernel<true>, grid, dim3(1024), lds, stream, pred, cell_idx, n_cells,
-                         slot_target, n_slots, A, H * W, capCells, dist);
-    else
-      hipLaunchKernelGGL(flm::distance_bfs_multi_kernel<false>, grid, dim3(1024), lds, stream, pred, cell_idx, n_cells,
-                         slot_target, n_slots, A, H * W, capCells, dist);
-    FLM_CHECK_LAUNCH();
-    return FLM_OK;
-  }
   const size_t pred_bytes = (capS * 8 + 15) & ~(size_t)15;
   const size_t per_wave = ((capS * 2 + 15) & ~(size_t)15) + ((((capS + 31) / 32) * 4 + 15) & ~(size_t)15);
   bool pred_lds = pred_bytes + 2 * per_wave <= kLdsBudget;

@@ -1,7 +1,6 @@
 // Path -> rail-occupancy plane, and the per-agent observation (own plane + two heat planes).
 #include "flm_common.h"
 
-int g_flm_dev_opt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // benchmark tuning hooks, see flm_dev_set_option
 
 namespace flm {
 
@@ -738,13 +737,6 @@ extern "C" int flm_bitmaps(const int32_t* path_cell, const int32_t* path_len, co
 }
 
 
-// Tuning hook for benchmarks (not part of the stable interface): key 0 = observation kernel variant.
-extern "C" int flm_dev_set_option(int key, int value) {
-  if (key < 0 || key >= 8) return FLM_E_ARG;
-  g_flm_dev_opt[key] = value;
-  return FLM_OK;
-}
-
 template <int APW, int CH, bool NT>
 static int launch_obs(const int8_t* maps, const int8_t* own, int E, int A, int plane_stride, uint8_t* obs, int nw,
                       hipStream_t stream) {
@@ -776,28 +768,16 @@ extern "C" int flm_observations(const int8_t* maps, const int8_t* own, int E, in
   if (!maps || !obs) return FLM_E_ARG;
   if (E <= 0 || E > 65535 || A <= 0 || A > 255 || plane_stride <= 0 || plane_stride % 16 != 0) return FLM_E_ARG;
   hipStream_t stream = (hipStream_t)stream_;
-  const int variant = g_flm_dev_opt[0];
-  // variant = nwsel + 10*chsel + 100*nt;  nwsel 0 auto, 1: 4 waves, 2: 8, 3: 16;  chsel 0: 1 chunk, 1: 2, 2: 4
-  // default: 16 waves (fewest agents per wave), non-temporal stores -- the fastest of the measured variants
-  int nwsel = variant % 10, chsel = (variant / 10) % 10, nt = variant == 0 ? 1 : (variant / 100) % 10;
-  int nw = 16;
-  if (nwsel == 1) nw = 4;
-  if (nwsel == 2) nw = 8;
-  if (nwsel == 3) nw = 16;
-  if (nw > A) nw = A;
-  if (chsel == 0) return nt ? launch_obs_apw<1, true>(maps, own, E, A, plane_stride, obs, nw, stream)
-                            : launch_obs_apw<1, false>(maps, own, E, A, plane_stride, obs, nw, stream);
-  if (chsel == 1) return nt ? launch_obs_apw<2, true>(maps, own, E, A, plane_stride, obs, nw, stream)
-                            : launch_obs_apw<2, false>(maps, own, E, A, plane_stride, obs, nw, stream);
-  return nt ? launch_obs_apw<4, true>(maps, own, E, A, plane_stride, obs, nw, stream)
-            : launch_obs_apw<4, false>(maps, own, E, A, plane_stride, obs, nw, stream);
+  // 16 waves (fewest agents per wave), 1 KiB per workgroup, non-temporal stores: the fastest of the measured shapes
+  const int nw = A < 16 ? A : 16;
+  return launch_obs_apw<1, true>(maps, own, E, A, plane_stride, obs, nw, stream);
 }
 
 template <int APW, int KT, int CH>
 static int launch_obs_cols(const int16_t* cols, int E, int A, int T1, int plane_stride, uint8_t* obs, int nw,
                            hipStream_t stream) {
   dim3 grid((plane_stride + 1024 * CH - 1) / (1024 * CH), E);
-  size_t lds = (size_t)CH * (2048 + 1024 * (size_t)nw) + (size_t)g_flm_dev_opt[3] * 1024;   // dev option 3: LDS padding in KiB (limits workgroups per CU)
+  size_t lds = (size_t)CH * (2048 + 1024 * (size_t)nw);
   if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(flm::observations_columns_kernel<APW, KT, CH>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return FLM_E_LAUNCH;
@@ -839,7 +819,7 @@ extern "C" int flm_observations_columns(const int16_t* cols, int E, int A, int R
   hipStream_t stream = (hipStream_t)stream_;
   int nw = A < 16 ? A : 16;
   // tile size: 1 KiB while an environment has few column entries, 2 or 4 KiB when scanning them dominates
-  int ch = g_flm_dev_opt[4] ? g_flm_dev_opt[4] : ((long)A * T1 >= 32768 ? 4 : (long)A * T1 >= 12288 ? 2 : 1);
+  const int ch = (long)A * T1 >= 32768 ? 4 : (long)A * T1 >= 12288 ? 2 : 1;
   if (ch >= 4) return launch_obs_cols_kt<4>(cols, E, A, T1, plane_stride, obs, nw, stream);
   if (ch >= 2) return launch_obs_cols_kt<2>(cols, E, A, T1, plane_stride, obs, nw, stream);
   return launch_obs_cols_kt<1>(cols, E, A, T1, plane_stride, obs, nw, stream);

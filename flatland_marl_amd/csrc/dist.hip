@@ -15,8 +15,6 @@
 // identical to a breadth-first search over the states, whatever the iteration order.
 #include "flm_common.h"
 
-extern int g_flm_dev_opt[8];
-
 namespace flm {
 
 #define FLM_NONE16 0xFFFFu
@@ -195,7 +193,7 @@ __global__ __launch_bounds__(FLM_DC_THREADS) void distance_chain_kernel(
     const int32_t* __restrict__ n_anchor_all, const int32_t* __restrict__ n_cells_all,
     const int32_t* __restrict__ cell_idx_all, const int32_t* __restrict__ slot_target,
     const int32_t* __restrict__ n_slots, int A, int HW, int capCells, int capAnch, int ldsAnch,
-    uint16_t* __restrict__ dist_all, int32_t* __restrict__ counts_all, int dbg) {
+    uint16_t* __restrict__ dist_all, int32_t* __restrict__ counts_all) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_cnt[FLM_DC_THREADS / 64][2];   // per wave: changed-list size, dirty-list size
   __shared__ int s_lost;                          // some pair did not fit a list
@@ -228,7 +226,6 @@ __global__ __launch_bounds__(FLM_DC_THREADS) void distance_chain_kernel(
   if (tid < 2 * (T / 64)) (&s_cnt[0][0])[tid] = 0;
   if (tid == 0) s_lost = 0;
   __syncthreads();
-  if (dbg & 8) return;
   // reverse adjacency (predecessor anchors)
   for (int a = tid; a < NA; a += T) {
     const uint4 eb = ed[a];
@@ -295,11 +292,8 @@ __global__ __launch_bounds__(FLM_DC_THREADS) void distance_chain_kernel(
     // list sizes live in (wave-uniform) registers; appends are placed by ballot ranks, so the only LDS
     // atomics left are the dirty-set updates, which rarely meet on one address
     int n_c = min(cnt[0], FLM_DC_LIST);
-    for (int round = 0; round < ((dbg & 1) ? 0 : 65536); round++) {
-      if (n_c == 0) {
-        if ((dbg & 16) && tid == 0) counts_all[e * 4 + 2] = round;
-        break;
-      }
+    for (int round = 0; round < 65536; round++) {
+      if (n_c == 0) break;
       // phase 1: predecessors of the changed pairs become dirty
       int n_d = 0;
       for (int base = 0; base < n_c; base += 64) {
@@ -395,8 +389,7 @@ __global__ __launch_bounds__(FLM_DC_THREADS) void distance_chain_kernel(
   }
   // every state: steps to its anchor + the anchor's distance.  A thread owns 8 consecutive states and
   // writes them to each target's row with one 16-byte store (rows are 16-byte aligned: capCells is even).
-  if (dbg & 4) return;
-  for (int s0 = tid * 8; s0 < ((dbg & 2) ? 0 : S); s0 += T * 8) {
+  for (int s0 = tid * 8; s0 < S; s0 += T * 8) {
     unsigned an[8], st[8];
     {
       const uint4 r4 = *reinterpret_cast<const uint4*>(root + s0);
@@ -469,7 +462,7 @@ extern "C" int flm_distance_chains(const uint16_t* root, const uint16_t* steps, 
     return FLM_E_LAUNCH;
   dim3 grid((A + 31) / 32, E);
   hipLaunchKernelGGL(flm::distance_chain_kernel, grid, dim3(FLM_DC_THREADS), lds, (hipStream_t)stream, root, steps, edges, n_anchor,
-                     n_cells, cell_idx, slot_target, n_slots, A, H * W, capCells, capAnch, ldsAnch, dist, counts, g_flm_dev_opt[2]);
+                     n_cells, cell_idx, slot_target, n_slots, A, H * W, capCells, capAnch, ldsAnch, dist, counts);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }

@@ -41,6 +41,15 @@ def max_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
+def min_over_ranks(value, device="cpu"):
+    """Smallest value of a python int over all ranks (how many collective steps every rank can take)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
+
+
 def sum_over_ranks(value, device="cpu"):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)

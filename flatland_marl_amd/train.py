@@ -17,6 +17,7 @@ come from one device generator; the switch-to-switch replay mode (src/main.py:28
 import numpy as np
 import torch
 
+from . import parallel
 from ._lib import call, ptr
 from .rollout import RolloutBatch
 
@@ -210,9 +211,15 @@ class BatchedTrainer:
             self.t_step = (self.t_step + n_new) % self.agent.args.update_every
             if self.max_learns_per_step is not None:
                 due = min(due, self.max_learns_per_step)
-            if len(self.replay) > self.agent.args.batch_size:
-                for _ in range(due):
-                    self._learn()
+            if len(self.replay) <= self.agent.args.batch_size:
+                due = 0
+        else:
+            due = 0
+        if train:
+            # data parallel: every learn step all-reduces the gradient, so all ranks take the same number
+            due = parallel.min_over_ranks(due, ro.device)
+            for _ in range(due):
+                self._learn()
         return n_new
 
     def run_episode(self, train=True):
@@ -225,7 +232,7 @@ class BatchedTrainer:
             self.step(train=train)
             total_reward += ro.reward.sum(dim=1)
             steps += 1
-            if bool(ro.all_done.all().item()):
+            if parallel.min_over_ranks(int(ro.all_done.all().item()), ro.device):   # every rank's environments are done
                 break
         self.eps = max(self.end_eps, self.eps_decay * self.eps)
         done_frac = ro.done.float().mean().item()

@@ -172,3 +172,20 @@ def test_long_horizon_uses_sequential_formulation():
     maps, _, errs = env.get_many()
     assert [ERR.get(x, 0) for x in errs] == list(b.agent_err[0].cpu().numpy())
     assert np.array_equal(b.maps_numpy(0), maps)
+
+
+@pytest.mark.parametrize("name", ["Test_1_Level_0", "Test_5_Level_1", "Test_8_Level_0"])
+def test_breadth_first_fallback_equals_chain_compression(name):
+    """The two distance methods give the same value for every valid state of every used row."""
+    import torch
+    fx = load_env(name)
+    b = _batch(fx, 150)
+    b.reset()
+    d0 = b.dist.clone()
+    b.dist.fill_(12345)
+    b.compute_distances(method="bfs")
+    torch.cuda.synchronize()
+    S = d0.shape[2]
+    valid = (torch.arange(S, device=d0.device)[None, None, :] < (b.n_cells * 4)[:, None, None]) & \
+            (torch.arange(b.A, device=d0.device)[None, :, None] < b.n_slots[:, None, None])
+    assert bool((d0[valid] == b.dist[valid]).all())

@@ -28,9 +28,10 @@ def _worker(rank, world, port, n_total, out_dir):
     mine = make_batch([fx], hi - lo, 5, seed=lo, square_only=True)
     t = parallel.max_over_ranks(1.0 + rank)
     total = parallel.sum_over_ranks(hi - lo)
+    fewest = parallel.min_over_ranks(3 + 2 * rank)
     g = torch.full((1000,), float(rank + 1))
     parallel.allreduce_mean_(g)
-    np.savez(os.path.join(out_dir, "r%d.npz" % rank), lo=lo, hi=hi, t=t, total=total, g=g.numpy(),
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), lo=lo, hi=hi, t=t, total=total, fewest=fewest, g=g.numpy(),
              start=mine["start"], target=mine["target"])
     dist.destroy_process_group()
 
@@ -43,6 +44,7 @@ def test_two_ranks_shard_and_reduce(tmp_path):
     assert int(r[0]["lo"]) == 0 and int(r[0]["hi"]) == int(r[1]["lo"]) and int(r[1]["hi"]) == n_total
     assert float(r[0]["t"]) == float(r[1]["t"]) == 2.0           # max over ranks
     assert float(r[0]["total"]) == float(r[1]["total"]) == n_total
+    assert int(r[0]["fewest"]) == int(r[1]["fewest"]) == 3          # learn steps every rank can take together
     assert np.allclose(r[0]["g"], 1.5) and np.allclose(r[1]["g"], 1.5)
     # shards are what a single process would have built for the same global environment indices
     from flatland_marl_amd.synthetic import make_batch

@@ -1,5 +1,5 @@
 """Development tool: replay one golden rollout trace step by step with host-side checks of every index the
-apply kernel consumes, printing progress (python tools/debug_rollout.py <trace.npz> [global])."""
+apply kernel consumes, printing progress (python tools/debug_rollout.py <trace.npz>)."""
 import os
 import sys
 
@@ -10,15 +10,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tests.golden_util import load_env  # noqa: E402
 from tests.test_gpu_rollout_batched import _rollout  # noqa: E402
-from flatland_marl_amd import _lib  # noqa: E402
 from flatland_marl_amd.rollout import hash_policy  # noqa: E402
 
 
 def main():
     path = sys.argv[1]
-    if len(sys.argv) > 2 and sys.argv[2] == "global":
-        _lib.load()
-        _lib.call("flm_dev_set_option", 5, 1)
     gold = dict(np.load(path))
     name = os.path.basename(path).split("_a")[0]
     A, depth, steps, Rp = int(gold["agents"]), int(gold["depth"]), int(gold["n_steps_run"]), int(gold["max_rails"])

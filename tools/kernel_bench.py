@@ -1,6 +1,6 @@
 """Per-kernel timings and variant sweeps on one GPU (development tool, not a test).
 
-    python tools/kernel_bench.py [--workload cfg3] [--envs E] [--obs-variants 0,100,...] [--bfs-variants 0,1]
+    python tools/kernel_bench.py [--workload cfg3] [--envs E]
 """
 import argparse
 import json
@@ -14,7 +14,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 import flatland_marl_amd as fm  # noqa: E402
-from flatland_marl_amd import _lib  # noqa: E402
 from flatland_marl_amd.synthetic import make_batch  # noqa: E402
 
 
@@ -35,8 +34,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="cfg3")
     ap.add_argument("--envs", type=int, default=0)
-    ap.add_argument("--obs-variants", default="0")
-    ap.add_argument("--bfs-variants", default="0")
     ap.add_argument("--stages", default="graph,bfs,paths,bitmaps,obs,fused")
     args = ap.parse_args()
     names, E, A, depth, desc = bench.WORKLOADS[args.workload]
@@ -56,15 +53,7 @@ def main():
         for m in ("chains", "bfs"):
             out["dist_ms_" + m] = timed(lambda: b.compute_distances(method=m))
             out["dist_equal_" + m] = bool(torch.equal(b.dist, ref_dist))
-        for dbg in (1, 2, 3, 4, 8):
-            _lib.call("flm_dev_set_option", 2, dbg)
-            out["dist_ms_chains_dbg%d" % dbg] = timed(lambda: b.compute_distances(method="chains"))[0]
-        _lib.call("flm_dev_set_option", 2, 16)
-        b.compute_distances(method="chains")
-        rounds = b.counts[:, 2].float()
-        out["rounds_mean_max"] = [float(rounds.mean()), float(rounds.max())]
         out["n_anchor_mean_max"] = [float(b.n_anchor.float().mean()), float(b.n_anchor.max()), b.lds_anchor]
-        _lib.call("flm_dev_set_option", 2, 0)
         b.compute_distances()
     if "paths" in stages:
         out["paths_ms"] = timed(b.shortest_paths)
@@ -81,16 +70,9 @@ def main():
                                 ok=int(b.obs.view(torch.int64).sum().item()) == ref_obs_sum)
     if "obs" in stages:
         alg = 4.0 * b.Rp * b.T1 * E * A
-        for v in [int(x) for x in args.obs_variants.split(",")]:
-            _lib.call("flm_dev_set_option", 0, v)
-            try:
-                b.obs.zero_()
-                t = timed(b.observations)
-                ok = int(b.obs.view(torch.int64).sum().item()) == ref_obs_sum
-                out["obs_v%d" % v] = dict(ms=t, GBs=alg / t[0] / 1e6, ok=ok)
-            except _lib.FlmError as ex:
-                out["obs_v%d" % v] = str(ex)
-        _lib.call("flm_dev_set_option", 0, 0)
+        b.obs.zero_()
+        t = timed(b.observations)
+        out["obs_dense"] = dict(ms=t, GBs=alg / t[0] / 1e6, ok=int(b.obs.view(torch.int64).sum().item()) == ref_obs_sum)
     print(json.dumps(out))
 
 
