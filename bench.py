@@ -79,7 +79,7 @@ def rollout_sample(device, steps=40):
     data = make_batch(load_fixtures(names), E, A, seed=0)
     b = fm.ObservationBatch(data["grid"], data["start"], data["direction"], data["target"], data["speed"], depth,
                             max_rails=100, device=device)
-    ro = RolloutBatch(b, data["speed"], data["direction"]).reset()
+    ro = RolloutBatch(b, data["speed"], data["direction"], max_alt_depth=max(200, depth + 1) + 2).reset()   # episodes of <= 200 steps (src/main.py:93)
     a = types.SimpleNamespace(prediction_depth=depth, lr=5e-5, buffer_size=20000, batch_size=512, update_every=10,
                               gamma=0.99, tau=1e-3)
     agent = DQNAgent(a, action_space=2, bitmap_height=3 * b.Rp)

@@ -51,7 +51,11 @@ struct GemmArgs {
   long a_zs, b_zs, c_zs;
   int relu, accumulate;
   int H3;              // EPI_CONV: rows are (b,h) with h < H3; C index = b*N*H3 + n*H3 + h
-  int ksplit;          // > 0: blockIdx.z selects the K range [z*ksplit, min(K, (z+1)*ksplit)), C += z*c_zs
+  int ksplit;          // > 0: blockIdx.z = group*nks + slice; the slice selects the K range
+                       // [slice*ksplit, min(K, (slice+1)*ksplit)) and C += slice*c_zs; the group (groups > 1)
+                       // selects an independent product: A += group*a_zs, B += group*b_zs, C += group*c_gs
+  int groups;
+  long c_gs;
 };
 
 #define GBM 128
@@ -115,10 +119,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
-  const float* A = g.A + (g.ksplit ? 0 : (long)blockIdx.z * g.a_zs);
-  const float* B = g.B + (g.ksplit ? 0 : (long)blockIdx.z * g.b_zs);
-  float* C = g.C + (long)blockIdx.z * g.c_zs;
-  const int k_begin = g.ksplit ? blockIdx.z * g.ksplit : 0;
+  const int nks = g.ksplit ? (int)gridDim.z / (g.groups > 1 ? g.groups : 1) : 1;
+  const int grp = g.ksplit ? (int)blockIdx.z / nks : (int)blockIdx.z;
+  const int slice = g.ksplit ? (int)blockIdx.z - grp * nks : 0;
+  const float* A = g.A + (long)grp * g.a_zs;
+  const float* B = g.B + (long)grp * g.b_zs;
+  float* C = g.C + (g.ksplit ? (long)slice * g.c_zs + (long)grp * g.c_gs : (long)grp * g.c_zs);
+  const int k_begin = slice * g.ksplit;
   const int k_end = g.ksplit ? min(g.K, k_begin + g.ksplit) : g.K;
   // 16-byte fetches need the rows 16-byte aligned
   const bool a_vec = (g.lda & 3) == 0 && (reinterpret_cast<size_t>(A) & 15) == 0;
@@ -201,14 +208,15 @@ __global__ void reduce_partials_kernel(const float* __restrict__ part, int nz, l
 }
 
 // out[m*ldo + n] = relu(bias[n] + sum over z of part[z][m][n])  (split-K reduction with the layer's epilogue)
-__global__ void reduce_bias_relu_kernel(const float* __restrict__ part, int nz, int M, int N, const float* __restrict__ bias,
-                                        float* __restrict__ out, long ldo) {
+// The bias of column n is bias0[n] for n < n_half and bias1[n - n_half] above (two layers side by side).
+__global__ void reduce_bias_relu_kernel(const float* __restrict__ part, int nz, int M, int N, const float* __restrict__ bias0,
+                                        const float* __restrict__ bias1, int n_half, float* __restrict__ out, long ldo) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)M * N) return;
   const int m = (int)(i / N), n = (int)(i - (long)m * N);
   float s = 0.f;
   for (int z = 0; z < nz; z++) s += part[(long)z * M * N + i];
-  s += bias[n];
+  s += n < n_half ? bias0[n] : bias1[n - n_half];
   out[(long)m * ldo + n] = s > 0.f ? s : 0.f;
 }
 
@@ -431,7 +439,16 @@ __global__ void obs_to_f32_kernel(const uint8_t* __restrict__ obs, int n, int Rp
 
 }  // namespace flm
 
-#define FLM_FC1_SPLITK 8   // K slices of the first dense layer at large batch
+// K slices of the first dense layer (advantage and value streams side by side: 8 column tiles): enough of
+// them that the launch has several workgroups per CU, which is what keeps the matrix pipes busy across the
+// barriers of the single-buffered K loop.
+static int fc1_k_slices(int B) {
+  const long tiles = (long)((B + GBM - 1) / GBM) * 8;
+  long n = (768 + tiles - 1) / tiles;
+  if (n < 1) n = 1;
+  if (n > 32) n = 32;
+  return (int)n;
+}
 
 using flm::DqnLayout;
 using flm::GemmArgs;
@@ -440,7 +457,7 @@ extern "C" long flm_dqn_param_count(int H3, int T1) { return DqnLayout(H3, T1).t
 
 // workspace floats needed by flm_dqn_forward for a batch of B samples
 extern "C" long flm_dqn_forward_workspace(int B, int H3) {
-  return (long)B * 64 * H3 + (long)B * 1024 + (long)FLM_FC1_SPLITK * B * 512;
+  return (long)B * 64 * H3 + (long)B * 1024 + (long)fc1_k_slices(B) * B * 1024;
 }
 
 static int dqn_forward_impl(const float* params, const float* x, int B, int H3, int T1, float* x1, float* hid, float* part,
@@ -460,20 +477,19 @@ static int dqn_forward_impl(const float* params, const float* x, int B, int H3, 
                        L.K1, hid + 512, 1024, 512);
     if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   } else {
-    // K = 64*H3 is long and M x N small: split K over workgroups, then reduce with bias + ReLU
-    const int nz = FLM_FC1_SPLITK;
-    const int ks = (int)(((L.K1 + nz - 1) / nz + GBK - 1) / GBK * GBK);
-    for (int s = 0; s < 2; s++) {
-      g = GemmArgs{};
-      g.A = x1; g.B = params + (s ? L.v1_w : L.a1_w); g.C = part;
-      g.M = B; g.N = 512; g.K = (int)L.K1; g.lda = L.K1; g.ldb = L.K1; g.ldc = 512;
-      g.c_zs = (long)B * 512; g.ksplit = ks;
-      rc = flm::launch_gemm<true, true, flm::EPI_PLAIN>(g, nz, stream);
-      if (rc) return rc;
-      const long ne = (long)B * 512;
-      hipLaunchKernelGGL(flm::reduce_bias_relu_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream, part, nz, B,
-                         512, params + (s ? L.v1_b : L.a1_b), hid + s * 512, 1024L);
-    }
+    // K = 64*H3 is long and M x N small: split K over workgroups, then reduce with bias + ReLU.  Both streams
+    // in one launch: group 0 = advantage, group 1 = value (their weight blocks are a fixed stride apart).
+    const int nks = fc1_k_slices(B);
+    const int ks = (int)(((L.K1 + nks - 1) / nks + GBK - 1) / GBK * GBK);
+    g = GemmArgs{};
+    g.A = x1; g.B = params + L.a1_w; g.C = part;
+    g.M = B; g.N = 512; g.K = (int)L.K1; g.lda = L.K1; g.ldb = L.K1; g.ldc = 1024;
+    g.a_zs = 0; g.b_zs = L.v1_w - L.a1_w; g.c_zs = (long)B * 1024; g.c_gs = 512; g.groups = 2; g.ksplit = ks;
+    rc = flm::launch_gemm<true, true, flm::EPI_PLAIN>(g, 2 * nks, stream);
+    if (rc) return rc;
+    const long ne = (long)B * 1024;
+    hipLaunchKernelGGL(flm::reduce_bias_relu_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream, part, nks, B,
+                       1024, params + L.a1_b, params + L.v1_b, 512, hid, 1024L);
   }
   hipLaunchKernelGGL(flm::head_forward_kernel, dim3(B), dim3(64), 0, stream, hid, params + L.a2_w, params + L.a2_b,
                      params + L.v2_w, params + L.v2_b, B, q);
@@ -505,7 +521,7 @@ extern "C" long flm_dqn_learn_workspace(int B, int H3, int T1) {
          + (long)B * 1024                                     // dhid
          + (long)B * 64 * H3                                  // dx1
          + (long)B * 64 * T1                                  // per-sample conv weight partials
-         + (long)FLM_FC1_SPLITK * B * 512                     // split-K partials of the first dense layer
+         + (long)fc1_k_slices(B) * B * 1024                   // split-K partials of the first dense layer
          + 16L * B + 64;                                      // q's, dq, dadv, dval, squared errors, loss
 }
 
@@ -526,7 +542,7 @@ extern "C" int flm_dqn_learn_grads(const float* local, const float* target, cons
   float* dx1 = dhid + n_hid;
   float* cpart = dx1 + n_x1;
   float* part = cpart + (long)B * 64 * T1;
-  float* q = part + (long)FLM_FC1_SPLITK * B * 512;
+  float* q = part + (long)fc1_k_slices(B) * B * 1024;
   float* qn = q + 2 * B; float* qt = qn + 2 * B; float* dq = qt + 2 * B;
   float* dadv = dq + 2 * B; float* dval = dadv + 2 * B; float* sq = dval + B;
   int rc;

@@ -28,6 +28,9 @@ class RolloutBatch:
         E, A, dev = b.E, b.A, b.device
         self.E, self.A, self.device = E, A, dev
         self.cap_alt = int(cap_alt)
+        # The reference asks for alternative paths of up to 500 moves (src/predictions.py:75).  An agent
+        # consumes at most one path element per environment step and a plane shows depth+1 steps, so in an
+        # episode of at most S steps a smaller max_alt_depth >= max(S, depth + 1) gives the same rollout.
         self.max_alt_depth = int(max_alt_depth)
         self.Lp = self.max_alt_depth + 40
         self.speed = torch.as_tensor(np.asarray(speed, np.float64).reshape(E, A), device=dev)

@@ -32,13 +32,14 @@ def main():
     ap.add_argument("--max-rails", type=int, default=0)
     ap.add_argument("--train", action="store_true")
     ap.add_argument("--eps", type=float, default=0.1)
+    ap.add_argument("--alt-depth", type=int, default=500)
     args = ap.parse_args()
     names, E, A, depth, desc = bench.WORKLOADS[args.workload]
     E = args.envs or E
     data = make_batch(bench.load_fixtures(names), E, A, seed=0)
     b = fm.ObservationBatch(data["grid"], data["start"], data["direction"], data["target"], data["speed"], depth,
                             max_rails=args.max_rails or None)
-    ro = RolloutBatch(b, data["speed"], data["direction"]).reset()
+    ro = RolloutBatch(b, data["speed"], data["direction"], max_alt_depth=args.alt_depth).reset()
     torch.cuda.synchronize()
     out = dict(workload=args.workload, E=E, A=A, Rp=int(b.Rp), T1=b.T1)
 

@@ -38,14 +38,12 @@ for k, c in mf.items():
     busy = sum(c.get("SQ_VALU_MFMA_BUSY_CYCLES", [0])) / max(1, len(c.get("SQ_VALU_MFMA_BUSY_CYCLES", [0])))
     gui = sum(c.get("GRBM_GUI_ACTIVE", [0])) / max(1, len(c.get("GRBM_GUI_ACTIVE", [0])))
     dq[k] = {"launches": len(c.get("GRBM_GUI_ACTIVE", [])), "SQ_VALU_MFMA_BUSY_CYCLES_avg": busy, "GRBM_GUI_ACTIVE_avg": gui,
-             "mfma_util_counter": busy / (gui / 8 * N_SIMD) if gui else None,
-             "mfma_util_issue": 2 * busy / (gui / 8 * N_SIMD) if gui else None}
+             "mfma_util": busy / (gui / 8 * N_SIMD) if gui else None}
 json.dump({"workload": "tools/dqn_bench.py (B=512, max_rails=100, depth 150), rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES "
-                       "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE", "mfma_util_counter": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); GRBM_GUI_ACTIVE is summed "
-                       "over the 8 XCDs (it reads 8x duration x clock)",
-           "mfma_util_issue": "the same x2: the counter advances 32 cycles per v_mfma_f32_32x32x2_f32 while the instruction "
-                       "occupies the pipe for 64 (4096 flop at 64 flop/clk/SIMD); this is the fraction of the fp32 matrix peak "
-                       "and agrees with flop / duration (fc1 GEMM: 20.1 GFLOP in 201 us = 100 TFLOP/s = 0.64 of 157)",
+                       "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE", "mfma_util": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); GRBM_GUI_ACTIVE is summed over the "
+                        "8 XCDs (it reads 8x duration x clock); the busy counter advances 64 cycles per v_mfma_f32_32x32x2_f32 "
+                        "(4096 flop at 64 flop/clk/SIMD), so this is the fraction of the fp32 matrix peak and agrees with "
+                        "flop / duration",
            "kernels": dq}, open(os.path.join(OUT, "%s_dqn_mfma.json" % tag), "w"), indent=1)
 
 # HBM traffic of the bench step: 64-byte write requests counted apart from 32-byte ones, reads likewise
@@ -69,5 +67,5 @@ json.dump({"workload": "cfg3 (bench.py --steps 2 --warmup 1), separate rocprofv3
 for k, v in tr.items():
     print("%-60s W %8.1f MB  R %8.1f MB" % (k[:60], v["write_bytes_per_launch"] / 1e6, v["read_bytes_per_launch"] / 1e6))
 for k, v in dq.items():
-    if v["mfma_util_issue"]:
-        print("%-60s mfma_util_issue %.3f" % (k[:60], v["mfma_util_issue"]))
+    if v["mfma_util"]:
+        print("%-60s mfma_util %.3f" % (k[:60], v["mfma_util"]))
