@@ -198,13 +198,24 @@ static int launch_gemm(const GemmArgs& g, int nz, hipStream_t stream) {
   return FLM_OK;
 }
 
-// out[n] = sum over z of part[z*n_elem + n]  (deterministic split-K reduction)
-__global__ void reduce_partials_kernel(const float* __restrict__ part, int nz, long n_elem, float* __restrict__ out) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_elem) return;
-  float s = 0.f;
-  for (int z = 0; z < nz; z++) s += part[(long)z * n_elem + i];
-  out[i] = s;
+// out[n] = sum over z of part[z*n_elem + n]  (deterministic reduction: 16 waves take every 16th slice each, their
+// sums meet in LDS in wave order)
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ part, int nz, long n_elem,
+                                                               float* __restrict__ out) {
+  __shared__ float s[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + lane;
+  float acc = 0.f;
+  if (i < n_elem)
+    for (int z = w; z < nz; z += 16) acc += part[(long)z * n_elem + i];
+  s[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && i < n_elem) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) t += s[k][lane];
+    out[i] = t;
+  }
 }
 
 // out[m*ldo + n] = relu(bias[n] + sum over z of part[z][m][n])  (split-K reduction with the layer's epilogue)
@@ -233,21 +244,24 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
 }
 
 // conv bias gradient: out[c] = sum over b,h of dX1[b][c][h]
-__global__ __launch_bounds__(256) void conv_bias_grad_kernel(const float* __restrict__ dX1, int B, int H3, float* __restrict__ out) {
-  __shared__ float s[256];
-  const int c = blockIdx.x;
+__global__ __launch_bounds__(1024) void conv_bias_grad_kernel(const float* __restrict__ dX1, int B, int H3, float* __restrict__ out) {
+  __shared__ float s[16];
+  const int c = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float acc = 0.f;
-  for (long i = threadIdx.x; i < (long)B * H3; i += 256) {
-    long b = i / H3, h = i - b * H3;
-    acc += dX1[(b * 64 + c) * H3 + h];
+  for (int b = w; b < B; b += 16) {
+    const float* row = dX1 + ((long)b * 64 + c) * H3;
+    for (int h = lane; h < H3; h += 64) acc += row[h];
   }
-  s[threadIdx.x] = acc;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) s[w] = acc;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
-    __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) t += s[k];
+    out[c] = t;
   }
-  if (threadIdx.x == 0) out[c] = s[0];
 }
 
 // ---- small-batch first dense layer (act: B <= 8): one wave per output neuron streams its weight row
@@ -333,12 +347,12 @@ __global__ void td_loss_kernel(const float* __restrict__ q, const float* __restr
   dq[b * 2 + (1 - a)] = 0.f;
 }
 
-__global__ void mean_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    float s = 0.f;
-    for (int i = 0; i < n; i++) s += x[i];
-    *out = s / (float)n;
-  }
+__global__ __launch_bounds__(64) void mean_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) s += x[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (threadIdx.x == 0) *out = s / (float)n;
 }
 
 // Backward of the head: from dq[B,2] to the hidden-layer gradient dhid[B,1024] (ReLU applied) and the
@@ -369,33 +383,55 @@ __global__ __launch_bounds__(64) void head_backward_hidden_kernel(const float* _
 }
 
 // g_a2w[a,i] = sum_b dadv[b,a]*hid[b,i]; g_a2b[a] = sum_b dadv[b,a]; g_v2w[i] = sum_b dval[b]*hid[b,512+i]; g_v2b
-__global__ __launch_bounds__(256) void head_backward_params_kernel(const float* __restrict__ hid, const float* __restrict__ dadv,
-                                                                   const float* __restrict__ dval, int B,
-                                                                   float* __restrict__ g_a2w, float* __restrict__ g_a2b,
-                                                                   float* __restrict__ g_v2w, float* __restrict__ g_v2b) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 512) {
-    float s0 = 0.f, s1 = 0.f, sv = 0.f;
-    for (int b = 0; b < B; b++) {
-      const float ha = hid[(long)b * 1024 + i], hv = hid[(long)b * 1024 + 512 + i];
-      s0 = fmaf(dadv[b * 2], ha, s0);
-      s1 = fmaf(dadv[b * 2 + 1], ha, s1);
-      sv = fmaf(dval[b], hv, sv);
-    }
-    g_a2w[i] = s0;
-    g_a2w[512 + i] = s1;
-    g_v2w[i] = sv;
+__global__ __launch_bounds__(1024) void head_backward_params_kernel(const float* __restrict__ hid, const float* __restrict__ dadv,
+                                                                    const float* __restrict__ dval, int B,
+                                                                    float* __restrict__ g_a2w, float* __restrict__ g_a2b,
+                                                                    float* __restrict__ g_v2w, float* __restrict__ g_v2b) {
+  // workgroup = 64 hidden units; 16 waves take every 16th sample each, their sums meet in LDS in wave order
+  __shared__ float s[3][16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, sv = 0.f;
+  for (int b = w; b < B; b += 16) {
+    const float ha = hid[(long)b * 1024 + i], hv = hid[(long)b * 1024 + 512 + i];
+    s0 = fmaf(dadv[b * 2], ha, s0);
+    s1 = fmaf(dadv[b * 2 + 1], ha, s1);
+    sv = fmaf(dval[b], hv, sv);
   }
-  if (i == 0) {
-    float s0 = 0.f, s1 = 0.f, sv = 0.f;
-    for (int b = 0; b < B; b++) {
-      s0 += dadv[b * 2];
-      s1 += dadv[b * 2 + 1];
-      sv += dval[b];
+  s[0][w][lane] = s0;
+  s[1][w][lane] = s1;
+  s[2][w][lane] = sv;
+  __syncthreads();
+  if (w == 0) {
+    float t0 = 0.f, t1 = 0.f, tv = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      t0 += s[0][k][lane];
+      t1 += s[1][k][lane];
+      tv += s[2][k][lane];
     }
-    g_a2b[0] = s0;
-    g_a2b[1] = s1;
-    g_v2b[0] = sv;
+    g_a2w[i] = t0;
+    g_a2w[512 + i] = t1;
+    g_v2w[i] = tv;
+  }
+  if (blockIdx.x == 0 && w == 1) {   // the three bias gradients: one wave, lanes stride over the batch
+    float b0 = 0.f, b1 = 0.f, bv = 0.f;
+    for (int b = lane; b < B; b += 64) {
+      b0 += dadv[b * 2];
+      b1 += dadv[b * 2 + 1];
+      bv += dval[b];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      b0 += __shfl_xor(b0, o);
+      b1 += __shfl_xor(b1, o);
+      bv += __shfl_xor(bv, o);
+    }
+    if (lane == 0) {
+      g_a2b[0] = b0;
+      g_a2b[1] = b1;
+      g_v2b[0] = bv;
+    }
   }
 }
 
@@ -555,7 +591,7 @@ extern "C" int flm_dqn_learn_grads(const float* local, const float* target, cons
   // head
   hipLaunchKernelGGL(flm::head_backward_hidden_kernel, dim3(B), dim3(64), 0, stream, hid, dq, local + L.a2_w, local + L.v2_w, B,
                      dhid, dadv, dval);
-  hipLaunchKernelGGL(flm::head_backward_params_kernel, dim3(2), dim3(256), 0, stream, hid, dadv, dval, B, grads + L.a2_w,
+  hipLaunchKernelGGL(flm::head_backward_params_kernel, dim3(8), dim3(1024), 0, stream, hid, dadv, dval, B, grads + L.a2_w,
                      grads + L.a2_b, grads + L.v2_w, grads + L.v2_b);
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   // first dense layer: weight gradients dW[n,j] = sum_b dhid[b,n] * x1[b,j]; bias gradients = column sums
@@ -584,9 +620,9 @@ extern "C" int flm_dqn_learn_grads(const float* local, const float* target, cons
     g.a_zs = 64L * H3; g.b_zs = (long)H3 * T1; g.c_zs = 64L * T1;
     if ((rc = flm::launch_gemm<true, false, flm::EPI_PLAIN>(g, B, stream))) return rc;
     const long ne = 64L * T1;
-    hipLaunchKernelGGL(flm::reduce_partials_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream, cpart, B, ne,
+    hipLaunchKernelGGL(flm::reduce_partials_kernel, dim3((unsigned)((ne + 63) / 64)), dim3(1024), 0, stream, cpart, B, ne,
                        grads + L.conv_w);
-    hipLaunchKernelGGL(flm::conv_bias_grad_kernel, dim3(64), dim3(256), 0, stream, dx1, B, H3, grads + L.conv_b);
+    hipLaunchKernelGGL(flm::conv_bias_grad_kernel, dim3(64), dim3(1024), 0, stream, dx1, B, H3, grads + L.conv_b);
   }
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
