@@ -473,6 +473,147 @@ __global__ void obs_to_f32_kernel(const uint8_t* __restrict__ obs, int n, int Rp
   }
 }
 
+// ---- convolution straight from uint8 observations ----------------------------------------------------
+// x1[b][c][h] = relu(bias[c] + sum_k W[c][k] * obs(b, h, k)) for the 64 filters, where row h = plane*Rp + rail
+// of an observation [3][plane_stride] (plane 0 holds int8, the heat planes uint8).  A workgroup owns 256
+// consecutive rows (b,h): their bytes (256 x T1) and the whole filter bank (T1 x 64 floats) sit in LDS, each
+// of the 4 waves multiplies 64 rows by the 64 filters on the matrix cores (2x2 tiles of 32x32), and the
+// result goes through LDS once more so that every filter's 256 outputs are stored contiguously.
+#define CV_ROWS 256
+#define CV_ASTRIDE(T1) ((((T1) + 6) / 4 * 4) | 4)              // bytes per row in LDS: covers 3 + T1 bytes, word count odd
+#define CV_WSTRIDE 65                                            // floats per k in LDS
+#define CV_SSTRIDE (CV_ROWS + 1)
+__global__ __launch_bounds__(256) void conv_u8_kernel(const uint8_t* __restrict__ obs, const float* __restrict__ Wc,
+                                                      const float* __restrict__ bias, long M, int Rp, int T1, int H3,
+                                                      int plane_stride, float* __restrict__ x1) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cv_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int astr = CV_ASTRIDE(T1);
+  const int KP = (T1 + 1) & ~1;                                  // K padded to a whole MFMA step
+  unsigned char* Ab = cv_lds;                                    // [CV_ROWS][astr]
+  float* Wl = reinterpret_cast<float*>(cv_lds + (((size_t)CV_ROWS * astr + 15) & ~(size_t)15));   // [KP][CV_WSTRIDE]
+  const long m0 = (long)blockIdx.x * CV_ROWS;
+  // rows: each wave copies its own 64 rows with aligned 4-byte loads, lanes along the row.  A row starts at any
+  // byte address, so its bytes keep their offset within the first word (0..3) in LDS too; the few bytes
+  // copied beyond the row meet zero filter weights (k >= T1).
+  {
+    const int nword = (T1 + 3 + 3) >> 2;                         // words that cover any alignment of T1 bytes
+    long m = m0 + wave * 64;
+    long b = m / H3;
+    int h = (int)(m - b * H3);
+    for (int r0 = wave * 64; r0 < wave * 64 + 64; r0 += 8) {     // 8 rows in flight per pass
+      for (int wb = 0; wb < nword; wb += 64) {
+        const int w = wb + lane;
+        unsigned v[8];
+        long bb = b;
+        int hh = h;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          v[i] = 0;
+          if (m + i < M && w < nword) {
+            const int pl = hh / Rp, rail = hh - pl * Rp;
+            const uint8_t* src = obs + ((size_t)bb * 3 + pl) * plane_stride + (size_t)rail * T1;
+            v[i] = reinterpret_cast<const unsigned*>(src - (reinterpret_cast<size_t>(src) & 3))[w];
+          }
+          if (++hh == H3) { hh = 0; bb++; }
+        }
+        if (w < nword) {
+#pragma unroll
+          for (int i = 0; i < 8; i++) reinterpret_cast<unsigned*>(Ab + (size_t)(r0 + i) * astr)[w] = v[i];
+        }
+      }
+      m += 8;
+      h += 8;
+      while (h >= H3) { h -= H3; b++; }
+    }
+  }
+  // filters, transposed to [k][c]: 8 loads in flight per thread
+  for (int i0 = 0; i0 < 64 * KP; i0 += 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int i = i0 + j * 256 + tid;
+      const int c = i / KP, k = i - c * KP;
+      v[j] = (i < 64 * KP && k < T1) ? Wc[(long)c * T1 + k] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int i = i0 + j * 256 + tid;
+      const int c = i / KP, k = i - c * KP;
+      if (i < 64 * KP) Wl[k * CV_WSTRIDE + c] = v[j];
+    }
+  }
+  __syncthreads();
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  const int c32 = lane & 31, kh = lane >> 5;
+  const int row0 = wave * 64 + c32, row1 = row0 + 32;
+  // plane 0 rows are signed
+  bool sg0, sg1;
+  {
+    const long ma = m0 + row0, mb = m0 + row1;
+    sg0 = (int)(ma % H3) < Rp;
+    sg1 = (int)(mb % H3) < Rp;
+  }
+  // byte offset of the row within its first word: the row's global address modulo 4
+  auto row_off = [&](long m) {
+    const long b = m / H3;
+    const int h = (int)(m - b * H3);
+    const int pl = h / Rp, rail = h - pl * Rp;
+    return (int)((reinterpret_cast<size_t>(obs) + ((size_t)b * 3 + pl) * plane_stride + (size_t)rail * T1) & 3);
+  };
+  const unsigned char* a0p = Ab + (size_t)row0 * astr + kh + row_off(m0 + row0);
+  const unsigned char* a1p = Ab + (size_t)row1 * astr + kh + row_off(m0 + row1);
+  const float* wp = Wl + kh * CV_WSTRIDE + c32;
+  for (int kk = 0; kk < KP; kk += 2) {
+    const unsigned u0 = a0p[kk], u1 = a1p[kk];
+    const float a0 = sg0 ? (float)(int)(signed char)u0 : (float)u0;
+    const float a1 = sg1 ? (float)(int)(signed char)u1 : (float)u1;
+    const float b0 = wp[kk * CV_WSTRIDE], b1 = wp[kk * CV_WSTRIDE + 32];
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+  }
+  __syncthreads();
+  // stage [filter][row] so that the stores run along the rows
+  float* S = reinterpret_cast<float*>(cv_lds);
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int c = j * 32 + c32;
+      const float bv = bias[c];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const float v = acc[i][j][r] + bv;
+        S[c * CV_SSTRIDE + row] = v > 0.f ? v : 0.f;
+      }
+    }
+  __syncthreads();
+  {
+    const long m = m0 + tid;
+    if (m < M) {
+      const long b = m / H3;
+      const int h = (int)(m - b * H3);
+      float* dst = x1 + (size_t)b * 64 * H3 + h;
+      for (int c = 0; c < 64; c++) dst[(size_t)c * H3] = S[c * CV_SSTRIDE + tid];
+    }
+  }
+}
+
+static size_t conv_u8_lds(int T1) {
+  const size_t a = (((size_t)CV_ROWS * CV_ASTRIDE(T1) + 15) & ~(size_t)15) + (size_t)((T1 + 1) & ~1) * CV_WSTRIDE * 4;
+  const size_t st = (size_t)64 * CV_SSTRIDE * 4;
+  return a > st ? a : st;
+}
+
 }  // namespace flm
 
 // K slices of the first dense layer (advantage and value streams side by side: 8 column tiles): enough of
@@ -496,16 +637,30 @@ extern "C" long flm_dqn_forward_workspace(int B, int H3) {
   return (long)B * 64 * H3 + (long)B * 1024 + (long)fc1_k_slices(B) * B * 1024;
 }
 
-static int dqn_forward_impl(const float* params, const float* x, int B, int H3, int T1, float* x1, float* hid, float* part,
-                            float* q, hipStream_t stream) {
+// x: float input [B,H3,T1], or nullptr when the input is obs_u8 [B,3,plane_stride] (H3 = 3*Rp)
+static int dqn_forward_impl(const float* params, const float* x, const uint8_t* obs_u8, int plane_stride, int B, int H3,
+                            int T1, float* x1, float* hid, float* part, float* q, hipStream_t stream) {
   DqnLayout L(H3, T1);
   GemmArgs g{};
-  // conv as GEMM: rows (b,h), K = T1, 64 filters; stored as [b][c][h] with ReLU
-  g.A = x; g.B = params + L.conv_w; g.C = x1; g.bias = params + L.conv_b; g.mask = nullptr;
-  g.M = B * H3; g.N = 64; g.K = T1; g.lda = T1; g.ldb = T1; g.ldc = 0; g.a_zs = g.b_zs = g.c_zs = 0;
-  g.relu = 1; g.accumulate = 0; g.H3 = H3;
-  int rc = flm::launch_gemm<true, true, flm::EPI_CONV>(g, 1, stream);
-  if (rc) return rc;
+  int rc;
+  if (x) {
+    // conv as GEMM: rows (b,h), K = T1, 64 filters; stored as [b][c][h] with ReLU
+    g.A = x; g.B = params + L.conv_w; g.C = x1; g.bias = params + L.conv_b; g.mask = nullptr;
+    g.M = B * H3; g.N = 64; g.K = T1; g.lda = T1; g.ldb = T1; g.ldc = 0; g.a_zs = g.b_zs = g.c_zs = 0;
+    g.relu = 1; g.accumulate = 0; g.H3 = H3;
+    rc = flm::launch_gemm<true, true, flm::EPI_CONV>(g, 1, stream);
+    if (rc) return rc;
+  } else {
+    const size_t lds = flm::conv_u8_lds(T1);
+    if (lds > 160 * 1024 - 512) return FLM_E_ARG;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flm::conv_u8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return FLM_E_LAUNCH;
+    const long M = (long)B * H3;
+    hipLaunchKernelGGL(flm::conv_u8_kernel, dim3((unsigned)((M + CV_ROWS - 1) / CV_ROWS)), dim3(256), lds, stream, obs_u8,
+                       params + L.conv_w, params + L.conv_b, M, H3 / 3, T1, H3, plane_stride, x1);
+    if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
+  }
   if (B <= 8 && (L.K1 & 3) == 0) {
     hipLaunchKernelGGL(flm::fc1_small_kernel<8>, dim3(128), dim3(256), 0, stream, x1, params + L.a1_w, params + L.a1_b, B,
                        L.K1, hid, 1024, 512);
@@ -539,7 +694,18 @@ extern "C" int flm_dqn_forward(const float* params, const float* x, int B, int H
   float* x1 = workspace;
   float* hid = workspace + (long)B * 64 * H3;
   float* part = hid + (long)B * 1024;
-  return dqn_forward_impl(params, x, B, H3, T1, x1, hid, part, q, (hipStream_t)stream);
+  return dqn_forward_impl(params, x, nullptr, 0, B, H3, T1, x1, hid, part, q, (hipStream_t)stream);
+}
+
+extern "C" int flm_dqn_forward_u8(const float* params, const uint8_t* obs, int n, int Rp, int T1, int plane_stride,
+                                  float* workspace, float* q, void* stream) {
+  if (!params || !obs || !workspace || !q || n <= 0 || Rp <= 0 || T1 <= 0 || (long)plane_stride < (long)Rp * T1)
+    return FLM_E_ARG;
+  const int H3 = 3 * Rp;
+  float* x1 = workspace;
+  float* hid = workspace + (long)n * 64 * H3;
+  float* part = hid + (long)n * 1024;
+  return dqn_forward_impl(params, nullptr, obs, plane_stride, n, H3, T1, x1, hid, part, q, (hipStream_t)stream);
 }
 
 extern "C" int flm_obs_to_f32(const uint8_t* obs, int n, int Rp, int T1, int plane_stride, float* out, void* stream) {
@@ -582,9 +748,9 @@ extern "C" int flm_dqn_learn_grads(const float* local, const float* target, cons
   float* qn = q + 2 * B; float* qt = qn + 2 * B; float* dq = qt + 2 * B;
   float* dadv = dq + 2 * B; float* dval = dadv + 2 * B; float* sq = dval + B;
   int rc;
-  if ((rc = dqn_forward_impl(local, s, B, H3, T1, x1, hid, part, q, stream))) return rc;
-  if ((rc = dqn_forward_impl(local, s_next, B, H3, T1, x1n, hidn, part, qn, stream))) return rc;
-  if ((rc = dqn_forward_impl(target, s_next, B, H3, T1, x1t, hidt, part, qt, stream))) return rc;
+  if ((rc = dqn_forward_impl(local, s, nullptr, 0, B, H3, T1, x1, hid, part, q, stream))) return rc;
+  if ((rc = dqn_forward_impl(local, s_next, nullptr, 0, B, H3, T1, x1n, hidn, part, qn, stream))) return rc;
+  if ((rc = dqn_forward_impl(target, s_next, nullptr, 0, B, H3, T1, x1t, hidt, part, qt, stream))) return rc;
   hipLaunchKernelGGL(flm::td_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, q, qn, qt, action, reward, done, gamma,
                      B, dq, sq);
   hipLaunchKernelGGL(flm::mean_kernel, dim3(1), dim3(64), 0, stream, sq, B, loss_out);

@@ -77,3 +77,17 @@ class Dueling_DQN(nn.Module):
         call("flm_dqn_forward", ptr(flat), ptr(x), B, self.height, self.width, ptr(self._workspace(B)), ptr(q),
              torch.cuda.current_stream(flat.device).cuda_stream)
         return q
+
+    def forward_obs(self, obs_u8, plane_stride):
+        """Q-values [n,2] straight from uint8 observations [n,3,plane_stride] (plane 0 int8, heat planes uint8,
+        rows of `width` bytes): the convolution reads the bytes, no float copy of the input is made."""
+        flat = self.flat_params()
+        if self.height % 3:
+            raise ValueError("observations have three planes: the network height must be 3*max_rails")
+        obs_u8 = obs_u8.contiguous()
+        n = obs_u8.size(0)
+        q = torch.empty((n, 2), dtype=torch.float32, device=flat.device)
+        call("flm_dqn_forward_u8", ptr(flat), ptr(obs_u8), n, self.height // 3, self.width, int(plane_stride),
+             ptr(self._workspace(n)), ptr(q), torch.cuda.current_stream(flat.device).cuda_stream)
+        return q
+

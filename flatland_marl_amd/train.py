@@ -53,12 +53,12 @@ class DQNPolicy:
         b = ro.b
         n = obs_u8.shape[0]
         q = torch.empty((n, 2), dtype=torch.float32, device=obs_u8.device)
-        per = 3 * b.Rp * b.T1 * 4
+        per = 64 * 3 * b.Rp * 4                            # the convolution output dominates the workspace
         chunk = max(1, self.chunk_bytes // per)
         net = self.agent.qnetwork_local
         for lo in range(0, n, chunk):
             hi = min(n, lo + chunk)
-            q[lo:hi] = net(obs_to_f32(obs_u8[lo:hi], b.Rp, b.T1, b.plane_stride))
+            q[lo:hi] = net.forward_obs(obs_u8[lo:hi], b.plane_stride)
         return q
 
     def __call__(self, ro, info):

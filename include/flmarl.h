@@ -274,6 +274,12 @@ long flm_dqn_learn_workspace(int B, int H3, int T1);        /* floats */
 int flm_dqn_forward(const float* params, const float* x, int B, int H3, int T1, float* workspace, float* q,
                     void* stream);
 
+/* The same forward pass straight from uint8 observations [n,3,plane_stride] (plane 0 int8, heat planes
+ * uint8, rows of T1 bytes: what flm_observations* write): the convolution reads the bytes, no float copy
+ * of the input is made.  workspace: flm_dqn_forward_workspace(n, 3*Rp) floats. */
+int flm_dqn_forward_u8(const float* params, const uint8_t* obs, int n, int Rp, int T1, int plane_stride,
+                       float* workspace, float* q, void* stream);
+
 /* uint8 observations [n,3,plane_stride] (own plane int8) -> float rows [n,3*Rp,T1], the network's input. */
 int flm_obs_to_f32(const uint8_t* obs, int n, int Rp, int T1, int plane_stride, float* out, void* stream);
 

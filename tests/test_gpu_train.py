@@ -42,6 +42,13 @@ def test_policy_q_values_match_act():
         state[0] = o[k, 0].view(np.int8)
         want = agent.act(state.reshape(3 * b.Rp, b.T1)).cpu().numpy()
         assert np.allclose(q[k], want, rtol=1e-5, atol=1e-6)
+    # the byte-input forward equals the float-input forward of the same observations
+    from flatland_marl_amd.train import obs_to_f32
+    qf = agent.qnetwork_local(obs_to_f32(obs, b.Rp, b.T1, b.plane_stride)).cpu().numpy()
+    assert np.allclose(q, qf, rtol=1e-5, atol=1e-6)
+    for n in (1, 3, 257):                                    # ragged row tiles and the small-batch dense layer
+        qa = agent.qnetwork_local.forward_obs(obs[:n], b.plane_stride).cpu().numpy()
+        assert np.allclose(qa, qf[:n], rtol=1e-5, atol=1e-6)
     # the observation of a request equals the all-agents sweep
     full = b.observations_fused()
     assert torch.equal(full.view(-1, 3, b.plane_stride)[req.long()], obs)

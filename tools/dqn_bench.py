@@ -50,6 +50,11 @@ def main():
     t = timed(lambda: agent.qnetwork_local(s))
     out["forward_ms"] = t
     out["forward_TFLOPs"] = fwd_flop / t / 1e9
+    ps = (a.max_rails * T1 + 255) // 256 * 256
+    obs = torch.randint(0, 3, (B, 3, ps), generator=g, dtype=torch.uint8).cuda()
+    t = timed(lambda: agent.qnetwork_local.forward_obs(obs, ps))
+    out["forward_u8_ms"] = t
+    out["forward_u8_TFLOPs"] = fwd_flop / t / 1e9
     t = timed(lambda: agent.learn((s, act, r, sn, d), 0.99))
     out["learn_ms"] = t
     out["learn_TFLOPs_5x_forward"] = 5 * fwd_flop / t / 1e9
