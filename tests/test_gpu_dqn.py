@@ -148,3 +148,30 @@ def test_gradients_elementwise_vs_torch(B, H3, T1):
         st = opt.state_dict()["state"]
         agent.optimizer.m.copy_(torch.cat([st[i]["exp_avg"].reshape(-1) for i in range(len(st))]))
         agent.optimizer.v.copy_(torch.cat([st[i]["exp_avg_sq"].reshape(-1) for i in range(len(st))]))
+
+
+@pytest.mark.parametrize("B,Rp,T1,pad", [(5, 10, 21, 0), (300, 7, 151, 3), (33, 4, 301, 1), (700, 100, 151, 0)])
+def test_forward_from_uint8_observations_vs_torch(B, Rp, T1, pad):
+    """The byte-input forward (convolution reads int8 / uint8 planes) against plain PyTorch fp32 on the same values;
+    plane strides that leave the rows at every byte alignment, horizons beyond 256 steps, ragged row tiles."""
+    from flatland_marl_amd.agent import DQNAgent
+    from tests.torch_ref_dqn import TorchDuelingDQN
+    torch.manual_seed(B)
+    H3 = 3 * Rp
+    args = argparse.Namespace(prediction_depth=T1 - 1, lr=0.001, buffer_size=10, batch_size=B, update_every=1,
+                              gamma=0.9, tau=0.05)
+    agent = DQNAgent(args, action_space=2, bitmap_height=H3)
+    ref = TorchDuelingDQN(T1, H3)
+    ref.load_state_dict(agent.qnetwork_local.state_dict())
+    ps = (Rp * T1 + 15) // 16 * 16 + 16 * pad
+    g = torch.Generator().manual_seed(B + 1)
+    obs = torch.zeros((B, 3, ps), dtype=torch.uint8)
+    own = torch.randint(-1, 2, (B, Rp * T1), generator=g)
+    obs[:, 0, :Rp * T1] = own.to(torch.int8).view(torch.uint8)
+    obs[:, 1, :Rp * T1] = torch.randint(0, 200, (B, Rp * T1), generator=g).to(torch.uint8)
+    obs[:, 2, :Rp * T1] = torch.randint(0, 255, (B, Rp * T1), generator=g).to(torch.uint8)
+    obs[:, :, Rp * T1:] = 77                     # bytes between planes must not leak into the result
+    x = torch.cat([own.float(), obs[:, 1, :Rp * T1].float(), obs[:, 2, :Rp * T1].float()], dim=1).view(B, 1, H3, T1)
+    want = ref(x).detach().numpy()
+    got = agent.qnetwork_local.forward_obs(obs.cuda(), ps).cpu().numpy()
+    assert close(got, want)
