@@ -31,7 +31,7 @@ __global__ __launch_bounds__(1024) void chain_index_kernel(
     const uint16_t* __restrict__ grid_all, const int32_t* __restrict__ cell_idx_all,
     const int32_t* __restrict__ n_cells_all, const int32_t* __restrict__ target_cell, int A, int H, int W, int capCells,
     int capAnch, uint16_t* __restrict__ root_all, uint16_t* __restrict__ steps_all, uint32_t* __restrict__ edges_all,
-    int32_t* __restrict__ n_anchor_all, int32_t* __restrict__ counts_all) {
+    int32_t* __restrict__ n_anchor_all, int32_t* __restrict__ counts_all, uint16_t* __restrict__ succ_all) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int e = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
   const int HW = H * W;
@@ -85,6 +85,10 @@ __global__ __launch_bounds__(1024) void chain_index_kernel(
       const bool is_target = (flags[s >> 5] >> (s & 31)) & 1;
       if (deg >= 2 && !is_target) atomicOr(&flags[s >> 5], 1u << (s & 31));
       const bool anchor = is_target || deg >= 2;
+      // forced step of a path walk: the heading allows exactly one exit (reported as "forward"), it leads to a
+      // rail cell, and the cell is neither a dead end nor a target
+      // (staged in the anchor-number array, which is not in use yet, and copied out with coalesced stores)
+      aidx[s] = (!is_target && deg == 1 && __popc(nib) == 1 && __popc(code & 0xFFFFu) != 1) ? (uint16_t)nxt : (uint16_t)FLM_NONE16;
       if (anchor || deg == 0) {
         jmp0[s] = (uint16_t)s;   // fixed point: anchors end a chain, dead states lead nowhere
         stp0[s] = 0;
@@ -95,6 +99,10 @@ __global__ __launch_bounds__(1024) void chain_index_kernel(
     }
   }
   __syncthreads();
+  if (succ_all) {
+    uint16_t* succ = succ_all + (size_t)e * capS;
+    for (int s = tid; s < S; s += T) succ[s] = aidx[s];
+  }
   // pointer doubling
   uint16_t* ja = jmp0; uint16_t* jb = jmp1; uint16_t* sa = stp0; uint16_t* sb = stp1;
   for (int span = 1; span < S; span <<= 1) {
@@ -427,7 +435,7 @@ __global__ __launch_bounds__(FLM_DC_THREADS) void distance_chain_kernel(
 extern "C" int flm_chain_index(const uint16_t* grid, const int32_t* cell_idx, const int32_t* n_cells,
                                const int32_t* target_cell, int E, int A, int H, int W, int capCells, int capAnch,
                                uint16_t* root, uint16_t* steps, uint32_t* edges, int32_t* n_anchor, int32_t* counts,
-                               void* stream) {
+                               uint16_t* succ, void* stream) {
   if (!grid || !cell_idx || !n_cells || !target_cell || !root || !steps || !edges || !n_anchor || !counts) return FLM_E_ARG;
   if (E <= 0 || A <= 0 || H <= 0 || W <= 0 || capCells <= 0 || capCells * 4 >= 65535 || capAnch <= 0 || capAnch > 0xFFF0)
     return FLM_E_ARG;
@@ -438,7 +446,7 @@ extern "C" int flm_chain_index(const uint16_t* grid, const int32_t* cell_idx, co
                           (int)lds) != hipSuccess)
     return FLM_E_LAUNCH;
   hipLaunchKernelGGL(flm::chain_index_kernel, dim3(E), dim3(1024), lds, (hipStream_t)stream, grid, cell_idx, n_cells,
-                     target_cell, A, H, W, capCells, capAnch, root, steps, edges, n_anchor, counts);
+                     target_cell, A, H, W, capCells, capAnch, root, steps, edges, n_anchor, counts, succ);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }

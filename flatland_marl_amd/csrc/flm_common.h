@@ -97,16 +97,49 @@ __device__ __forceinline__ int block_int_scan256(int v, int* scratch, int* total
 // to tcell: at most max_depth moves, ties broken left, forward, right; the best distance seen so far is
 // carried from step to step.  Elements are written while they fit in cap.  Returns the element count
 // (may exceed cap), or -1 when some step has no admissible move.
+// succ (optional): for every state with exactly one possible move that is not on any target cell, the
+// state that move leads to (0xFFFF otherwise).  Such a step needs no distance look-up: on a reachable
+// state the single successor is one move closer, so the walk follows succ and only evaluates candidates
+// where there is a choice.
 __device__ __forceinline__ int greedy_path(const uint16_t* __restrict__ grid, const int32_t* __restrict__ cell_idx,
-                                           const uint16_t* __restrict__ dist, int H, int W, int cell, int h, int tcell,
-                                           int max_depth, int32_t* pc, uint32_t* pm, int cap) {
+                                           const uint16_t* __restrict__ dist, const uint16_t* __restrict__ succ, int H, int W,
+                                           int cell, int h, int tcell, int max_depth, int32_t* pc, uint32_t* pm, int cap) {
   unsigned best_d = 0xFFFFFFFFu;
   int n = 0, depth = 0;
+  int s = -1;                 // compact state number of (cell, h) while it is known
+  bool reach = false;         // the current state is known to reach the target, best_d is its distance
+  if (succ && cell >= 0 && cell < H * W) {
+    const int idx = cell_idx[cell];
+    if (idx >= 0) s = idx * 4 + h;
+  }
   while (cell != tcell && depth < max_depth) {
+    if (s >= 0) {
+      const unsigned nx = succ[s];
+      if (nx != 0xFFFFu) {
+        if (!reach) {
+          const unsigned d0 = dist[s];
+          if (d0 == FLM_DIST_INF) return -1;      // nothing can be reached from here
+          best_d = d0;
+          reach = true;
+        }
+        const int nd = (int)(nx & 3u);
+        if (n < cap) {
+          pc[n] = cell;
+          pm[n] = (unsigned)h | (2u << 8) | ((unsigned)nd << 16);
+        }
+        n++;
+        depth++;
+        cell += dr(nd) * W + dc(nd);
+        h = nd;
+        s = (int)nx;
+        best_d -= 1;
+        continue;
+      }
+    }
     int r = cell / W, c = cell - r * W;
     int act[3], nd[3];
     int k = valid_moves(grid[cell], h, act, nd);
-    int best = -1;
+    int best = -1, best_idx = -1;
     for (int i = 0; i < k; i++) {
       int nr = r + dr(nd[i]), nc = c + dc(nd[i]);
       if (nr < 0 || nr >= H || nc < 0 || nc >= W) continue;
@@ -116,6 +149,7 @@ __device__ __forceinline__ int greedy_path(const uint16_t* __restrict__ grid, co
       if (dd != FLM_DIST_INF && dd < best_d) {
         best = i;
         best_d = dd;
+        best_idx = idx;
       }
     }
     if (best < 0) return -1;
@@ -127,6 +161,8 @@ __device__ __forceinline__ int greedy_path(const uint16_t* __restrict__ grid, co
     depth++;
     cell = (r + dr(nd[best])) * W + c + dc(nd[best]);
     h = nd[best];
+    if (succ) s = best_idx * 4 + h;
+    reach = true;
   }
   if (depth < max_depth) {  // closing element: stop on the cell reached
     if (n < cap) {

@@ -11,8 +11,8 @@ namespace flm {
 #define FLM_ALT_STACK 32
 
 __global__ void altpaths_kernel(const uint16_t* __restrict__ grid_all, const int32_t* __restrict__ cell_idx_all,
-                                const uint16_t* __restrict__ dist_all, const int32_t* __restrict__ tslot,
-                                const int32_t* __restrict__ node_id_all, const int32_t* __restrict__ req_agent, int n_req,
+                                const uint16_t* __restrict__ dist_all, const uint16_t* __restrict__ succ_all,
+                                const int32_t* __restrict__ tslot, const int32_t* __restrict__ node_id_all, const int32_t* __restrict__ req_agent, int n_req,
                                 const int32_t* __restrict__ pos_cell, const int32_t* __restrict__ direction,
                                 const int32_t* __restrict__ target_cell, int A, int H, int W, int capCells,
                                 int max_depth, int cap_alt, int Lcap, int32_t* __restrict__ alt_count,
@@ -27,6 +27,7 @@ __global__ void altpaths_kernel(const uint16_t* __restrict__ grid_all, const int
   const int32_t* cell_idx = cell_idx_all + (size_t)e * HW;
   const int32_t* node_id = node_id_all + (size_t)e * HW;
   const uint16_t* dist = dist_all + ((size_t)e * A + tslot[ga]) * capCells * 4;
+  const uint16_t* succ = succ_all ? succ_all + (size_t)e * capCells * 4 : nullptr;
   const int tcell = target_cell[ga];
   const int pos = pos_cell[ga], h0 = direction[ga] & 3;
   int32_t* out_len = alt_len + (size_t)g * cap_alt;
@@ -94,7 +95,7 @@ __global__ void altpaths_kernel(const uint16_t* __restrict__ grid_all, const int
             int nr = r + dr(f_nd[d][0]), nc = c + dc(f_nd[d][0]);
             int n = -1;
             if (nr >= 0 && nr < H && nc >= 0 && nc < W)
-              n = greedy_path(grid, cell_idx, dist, H, W, nr * W + nc, f_nd[d][0], tcell, max_depth, oc + base, om + base,
+              n = greedy_path(grid, cell_idx, dist, succ, H, W, nr * W + nc, f_nd[d][0], tcell, max_depth, oc + base, om + base,
                               Lcap - base);
             if (n >= 0) {
               if (base + n > Lcap) { err = FLM_AGENT_OVERFLOW; break; }
@@ -298,8 +299,8 @@ __global__ __launch_bounds__(256) void update_bitmaps_kernel(int8_t* __restrict_
 
 }  // namespace flm
 
-extern "C" int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const uint16_t* dist, const int32_t* tslot,
-                            const int32_t* node_id, const int32_t* req_agent, int n_req, const int32_t* pos_cell,
+extern "C" int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const uint16_t* dist, const uint16_t* succ,
+                            const int32_t* tslot, const int32_t* node_id, const int32_t* req_agent, int n_req, const int32_t* pos_cell,
                             const int32_t* direction, const int32_t* target_cell, int E, int A, int H, int W,
                             int capCells, int max_depth, int cap_alt, int Lcap, int32_t* alt_count, int32_t* alt_len,
                             int32_t* alt_cell, uint32_t* alt_meta, int32_t* err, void* stream) {
@@ -310,7 +311,7 @@ extern "C" int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const
       Lcap < max_depth + 4)
     return FLM_E_ARG;
   hipLaunchKernelGGL(flm::altpaths_kernel, dim3((n_req + 63) / 64), dim3(64), 0, (hipStream_t)stream, grid, cell_idx, dist,
-                     tslot, node_id, req_agent, n_req, pos_cell, direction, target_cell, A, H, W, capCells, max_depth,
+                     succ, tslot, node_id, req_agent, n_req, pos_cell, direction, target_cell, A, H, W, capCells, max_depth,
                      cap_alt, Lcap, alt_count, alt_len, alt_cell, alt_meta, err);
   FLM_CHECK_LAUNCH();
   return FLM_OK;

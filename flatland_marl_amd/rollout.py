@@ -123,7 +123,8 @@ class RolloutBatch:
                    col_err=torch.empty((n, K), **i32), req=req)
         for lo in range(0, n, MAX_REQ):
             hi = min(n, lo + MAX_REQ)
-            call("flm_altpaths", ptr(b.grid), ptr(b.cell_idx), ptr(b.dist), ptr(b.tslot), ptr(b.node_id), ptr(req[lo:hi]),
+            call("flm_altpaths", ptr(b.grid), ptr(b.cell_idx), ptr(b.dist), ptr(b.succ_table()), ptr(b.tslot), ptr(b.node_id),
+                 ptr(req[lo:hi]),
                  hi - lo, ptr(b.pos_cell), ptr(b.direction), ptr(b.target_cell), self.E, self.A, b.H, b.W, b.cap_cells,
                  self.max_alt_depth, K, self.Lp, ptr(alt["count"][lo:hi]), ptr(alt["len"][lo:hi]), ptr(alt["cell"][lo:hi]),
                  ptr(alt["meta"][lo:hi]), ptr(alt["err"][lo:hi]), self.stream)

@@ -96,7 +96,10 @@ int flm_distance_bfs(const uint16_t* pred, const int32_t* cell_idx, const int32_
  *                      steps [E,capCells*4] uint16 = moves to get there; edges [E,capAnch,4] uint32 =
  *                      anchor | weight<<16 per move of an anchor; n_anchor [E]; sets FLM_GRAPH_ERR_STATES
  *                      in counts[e*4+3] when capAnch is too small.  Needs cell_idx/n_cells of
- *                      flm_state_index and the agents' target cells;
+ *                      flm_state_index and the agents' target cells; succ [E,capCells*4] uint16 (may be NULL)
+ *                      out: the state a forced move leads to (one exit in the heading's transitions, the cell
+ *                      neither a dead end nor a target), 0xFFFF otherwise: the path walks below follow it
+ *                      without distance look-ups;
  *   flm_distance_chains  dist [E,A,capCells*4] as flm_distance_bfs; ldsAnch <= capAnch is the number of
  *                      anchors the workgroup's LDS tables are sized for (80 bytes each); an environment
  *                      with more anchors is flagged in counts[e*4+3] and its rows are left unwritten. */
@@ -104,7 +107,7 @@ int flm_target_slots(const int32_t* target_cell, int E, int A, int32_t* tslot, i
                      void* stream);
 int flm_chain_index(const uint16_t* grid, const int32_t* cell_idx, const int32_t* n_cells, const int32_t* target_cell,
                     int E, int A, int H, int W, int capCells, int capAnch, uint16_t* root, uint16_t* steps,
-                    uint32_t* edges, int32_t* n_anchor, int32_t* counts, void* stream);
+                    uint32_t* edges, int32_t* n_anchor, int32_t* counts, uint16_t* succ, void* stream);
 int flm_distance_chains(const uint16_t* root, const uint16_t* steps, const uint32_t* edges, const int32_t* n_anchor,
                         const int32_t* n_cells, const int32_t* cell_idx, const int32_t* slot_target,
                         const int32_t* n_slots, int E, int A, int H, int W, int capCells, int capAnch, int ldsAnch,
@@ -115,8 +118,9 @@ int flm_distance_chains(const uint16_t* root, const uint16_t* steps, const uint3
  *   start_cell/start_dir [E,A] int32: the position chosen at :38-49; status [E,A] int32
  *   path_cell [E,A,Lcap] int32, path_meta [E,A,Lcap] uint32 = heading | action<<8 | next heading<<16
  *   (next cell = cell + move(next heading), or the same cell when action == 4)
- *   path_len  [E,A] int32, -1 = None.  Lcap >= max_depth + 1. */
-int flm_shortest_paths(const uint16_t* grid, const int32_t* cell_idx, const uint16_t* dist,
+ *   path_len  [E,A] int32, -1 = None.  Lcap >= max_depth + 1.
+ *   succ: the table written by flm_chain_index for the same targets, or NULL (same paths, more look-ups). */
+int flm_shortest_paths(const uint16_t* grid, const int32_t* cell_idx, const uint16_t* dist, const uint16_t* succ,
                        const int32_t* tslot, const int32_t* start_cell, const int32_t* start_dir,
                        const int32_t* target_cell, const int32_t* status, int E, int A, int H, int W,
                        int capCells, int max_depth, int Lcap, int32_t* path_cell, uint32_t* path_meta,
@@ -195,8 +199,8 @@ int flm_reorder_rails(const uint8_t* obs_in, uint8_t* obs_out, int n, int Rp, in
  *   assertions at :108/:125 fail, FLM_AGENT_OVERFLOW when cap_alt, Lcap or 32 consecutive switch cells
  *   are exceeded).  Lcap >= max_depth + 4.
  * Alternatives come in the reference's order: moves left, forward, right, depth first. */
-int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const uint16_t* dist, const int32_t* tslot,
-                 const int32_t* node_id, const int32_t* req_agent, int n_req, const int32_t* pos_cell,
+int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const uint16_t* dist, const uint16_t* succ,
+                 const int32_t* tslot, const int32_t* node_id, const int32_t* req_agent, int n_req, const int32_t* pos_cell,
                  const int32_t* direction, const int32_t* target_cell, int E, int A, int H, int W, int capCells,
                  int max_depth, int cap_alt, int Lcap, int32_t* alt_count, int32_t* alt_len, int32_t* alt_cell,
                  uint32_t* alt_meta, int32_t* err, void* stream);
