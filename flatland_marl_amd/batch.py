@@ -87,7 +87,7 @@ class ObservationBatch:
         self.counts = torch.zeros((E, 4), **i32)
         self.cell_idx = torch.empty((E, HW), **i32)
         self.n_cells = torch.empty((E,), **i32)
-        self.pred = torch.empty((E, self.cap_cells * 4, 4), dtype=torch.int16, device=dev)
+        self.pred = None     # reverse-move table: only the breadth-first fallback needs it
 
     def _launch_graph(self):
         E, H, W = self.E, self.H, self.W
@@ -96,7 +96,7 @@ class ObservationBatch:
              ptr(self.node_cell), ptr(self.edge_info), ptr(self.edge_cell_off), ptr(self.edge_cells),
              ptr(self.cell_rail), ptr(self.counts), s)
         call("flm_state_index", ptr(self.grid), E, H, W, self.cap_cells, ptr(self.cell_idx), ptr(self.n_cells),
-             ptr(self.pred), ptr(self.counts), s)
+             None, ptr(self.counts), s)
 
     def build_graph(self, sync=True):
         """Switch graph + cell->rail table + state numbering for the BFS.
@@ -167,6 +167,10 @@ class ObservationBatch:
             method = "chains" if capS * 10 + capS // 8 + 512 <= 159 * 1024 else "bfs"
         if method == "bfs":
             self._succ_valid = False
+            if self.pred is None:
+                self.pred = torch.empty((E, capS, 4), dtype=torch.int16, device=dev)
+            call("flm_state_index", ptr(self.grid), E, self.H, self.W, self.cap_cells, ptr(self.cell_idx),
+                 ptr(self.n_cells), ptr(self.pred), ptr(self.counts), s)
             call("flm_distance_bfs", ptr(self.pred), ptr(self.cell_idx), ptr(self.n_cells), ptr(self.target_cell), E,
                  A, self.H, self.W, self.cap_cells, ptr(self.tslot), ptr(self.n_slots), ptr(self.slot_target),
                  ptr(self.dist), s)

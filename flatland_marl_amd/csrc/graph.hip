@@ -196,21 +196,32 @@ __global__ __launch_bounds__(256) void graph_build_kernel(
   }
 }
 
-// Compact numbering of rail cells + reverse-move table, one workgroup per environment.
-__global__ __launch_bounds__(256) void state_index_kernel(const uint16_t* __restrict__ grid_all, int H, int W, int capCells,
-                                                          int32_t* __restrict__ cell_idx_all, int32_t* __restrict__ n_cells_all,
-                                                          uint16_t* __restrict__ pred_all, int32_t* __restrict__ counts_all) {
-  __shared__ int scratch[8];
+// Compact numbering of rail cells + (optionally) the reverse-move table, one 1024-thread workgroup per environment.
+__global__ __launch_bounds__(1024) void state_index_kernel(const uint16_t* __restrict__ grid_all, int H, int W, int capCells,
+                                                           int32_t* __restrict__ cell_idx_all, int32_t* __restrict__ n_cells_all,
+                                                           uint16_t* __restrict__ pred_all, int32_t* __restrict__ counts_all) {
+  __shared__ int wave_tot[16];
   const int e = blockIdx.x, tid = threadIdx.x, HW = H * W;
+  const int wave = tid >> 6;
   const uint16_t* grid = grid_all + (size_t)e * HW;
   int32_t* cell_idx = cell_idx_all + (size_t)e * HW;
-  uint16_t* pred = pred_all + (size_t)e * capCells * 16;
   int n = 0;
-  for (int base = 0; base < HW; base += 256) {
-    int cell = base + tid;
-    bool rail = cell < HW && grid[cell] != 0;
-    int tot;
-    int id = n + block_flag_scan256(rail, scratch, &tot);
+  for (int base = 0; base < HW; base += 1024) {
+    const int cell = base + tid;
+    const bool rail = cell < HW && grid[cell] != 0;
+    // 1024-thread flag scan: ballot per wave + wave totals through LDS
+    const unsigned long long m = __ballot(rail);
+    if ((tid & 63) == 0) wave_tot[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int v = wave_tot[i];
+      if (i < wave) before += v;
+      tot += v;
+    }
+    __syncthreads();
+    const int id = n + before + __popcll(m & lanemask_lt());
     if (cell < HW) cell_idx[cell] = (rail && id < capCells) ? id : -1;
     n += tot;
   }
@@ -218,9 +229,11 @@ __global__ __launch_bounds__(256) void state_index_kernel(const uint16_t* __rest
     n_cells_all[e] = n > capCells ? capCells : n;
     if (n > capCells) atomicOr(&counts_all[e * 4 + 3], FLM_GRAPH_ERR_STATES);
   }
+  if (!pred_all) return;
   __syncthreads();
+  uint16_t* pred = pred_all + (size_t)e * capCells * 16;
   // state (cell, h) is reached in one move from (cell - move(h), o) for every o allowed to leave towards h
-  for (int cell = tid; cell < HW; cell += 256) {
+  for (int cell = tid; cell < HW; cell += 1024) {
     int idx = cell_idx[cell];
     if (idx < 0) continue;
     int r = cell / W, c = cell - r * W;
@@ -274,9 +287,9 @@ extern "C" int flm_graph_build(const uint16_t* grid, int E, int H, int W, int ca
 
 extern "C" int flm_state_index(const uint16_t* grid, int E, int H, int W, int capCells, int32_t* cell_idx,
                                int32_t* n_cells, uint16_t* pred, int32_t* counts, void* stream) {
-  if (!grid || !cell_idx || !n_cells || !pred || !counts) return FLM_E_ARG;
+  if (!grid || !cell_idx || !n_cells || !counts) return FLM_E_ARG;   // pred may be NULL: numbering only
   if (E <= 0 || H <= 0 || W <= 0 || capCells <= 0 || capCells * 4 >= 65535) return FLM_E_ARG;
-  hipLaunchKernelGGL(flm::state_index_kernel, dim3(E), dim3(256), 0, (hipStream_t)stream, grid, H, W, capCells,
+  hipLaunchKernelGGL(flm::state_index_kernel, dim3(E), dim3(1024), 0, (hipStream_t)stream, grid, H, W, capCells,
                      cell_idx, n_cells, pred, counts);
   FLM_CHECK_LAUNCH();
   return FLM_OK;

@@ -73,7 +73,8 @@ int flm_graph_build(const uint16_t* grid, int E, int H, int W, int capN, int cap
  * src/utils/shortest_path.py:60-62.
  *   cell_idx [E,H*W] int32 (-1 = empty cell), n_cells [E] int32,
  *   pred     [E,capCells*4,4] uint16: for state cell_idx*4+heading, the states that reach it in one move
- *            (0xFFFF = none).  capCells*4 < 65535.  counts[e*4+3] gets FLM_GRAPH_ERR_STATES on overflow. */
+ *            (0xFFFF = none); NULL = numbering only (the chain-compressed distances do not need it).
+ *            capCells*4 < 65535.  counts[e*4+3] gets FLM_GRAPH_ERR_STATES on overflow. */
 int flm_state_index(const uint16_t* grid, int E, int H, int W, int capCells, int32_t* cell_idx,
                     int32_t* n_cells, uint16_t* pred, int32_t* counts, void* stream);
 
