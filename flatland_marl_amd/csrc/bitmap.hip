@@ -817,7 +817,7 @@ extern "C" int flm_observations_columns(const int16_t* cols, int E, int A, int R
       (long long)plane_stride < (long long)Rp * T1)
     return FLM_E_ARG;
   hipStream_t stream = (hipStream_t)stream_;
-  int nw = A < 16 ? A : 16;
+  const int nw = A < 16 ? A : 16;
   // tile size: 1 KiB while an environment has few column entries, 2 or 4 KiB when scanning them dominates
   const int ch = (long)A * T1 >= 32768 ? 4 : (long)A * T1 >= 12288 ? 2 : 1;
   if (ch >= 4) return launch_obs_cols_kt<4>(cols, E, A, T1, plane_stride, obs, nw, stream);
