@@ -193,7 +193,7 @@ class ObservationBatch:
             # The LDS tables are sized for the count seen now plus a margin for later target assignments;
             # an environment that outgrows it is flagged in counts (check_graph) and this size is recomputed.
             n_now = int(self.n_anchor.max().item())
-            fit = (159 * 1024 - 8 * 2 * 512 * 2 - 128) // 100
+            fit = (159 * 1024 - 16 * 2 * 256 * 2 - 128) // 100
             self.lds_anchor = int(min(self.cap_anchor, n_now + min(4 * A, 64), max(fit, 1), 2047))
             if self.lds_anchor < n_now:
                 return self.compute_distances(method="bfs")

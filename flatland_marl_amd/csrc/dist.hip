@@ -183,7 +183,7 @@ __global__ __launch_bounds__(1024) void chain_index_kernel(
 
 // One workgroup per (environment, 32 target slots).  LDS per anchor: its forward edges, its distance for
 // each of the 32 targets, its predecessors (reverse edges) and a 32-bit "dirty" set.  Targets are
-// independent problems, so each of the 8 waves owns 4 of them and iterates on its own, without workgroup
+// independent problems, so each of the 16 waves owns 2 of them and iterates on its own, without workgroup
 // barriers (a wave's LDS operations complete in program order).  Per wave, work lists hold (anchor, target)
 // pairs packed in 16 bits.  A round has two phases, one lane per pair:
 //   1. every pair whose label got smaller marks the same target dirty at the anchor's predecessors; a
@@ -193,8 +193,11 @@ __global__ __launch_bounds__(1024) void chain_index_kernel(
 // Each label has one writer per round.  If a list ever fills up, the pairs that did not fit are made up
 // for after the rounds by sweeping all labels until nothing changes (labels are always lengths of real
 // paths, so the sweep converges to the same shortest distances).
-#define FLM_DC_THREADS 512
-#define FLM_DC_LIST 512    // pairs per wave and list
+#define FLM_DC_THREADS 1024
+#define FLM_DC_LIST 256    // pairs per wave and list
+#ifndef FLM_DC_WAVES
+#define FLM_DC_WAVES 16     // waves that iterate (32 / FLM_DC_WAVES targets each); the other waves only help to set up and fill
+#endif
 #define FLM_DA_ROW 34   // uint16 per anchor row: 32 targets + 2 of padding, so that rows start on different LDS banks
 __global__ __launch_bounds__(FLM_DC_THREADS) void distance_chain_kernel(
     const uint16_t* __restrict__ root_all, const uint16_t* __restrict__ steps_all, const uint32_t* __restrict__ edges_all,
@@ -276,12 +279,12 @@ __global__ __launch_bounds__(FLM_DC_THREADS) void distance_chain_kernel(
   __syncthreads();
   {
     const int w = tid >> 6, lane = tid & 63;
-    uint16_t* lc = lists + (size_t)w * 2 * FLM_DC_LIST;   // changed pairs
+    uint16_t* lc = lists + (size_t)(w < FLM_DC_WAVES ? w : 0) * 2 * FLM_DC_LIST;   // changed pairs
     uint16_t* ld = lc + FLM_DC_LIST;                      // dirty pairs
     int* cnt = s_cnt[w];
-    // sources: the four states of each target cell (this wave's targets are w, w+8, w+16, w+24)
-    if (lane < 16) {
-      const int j = w + 8 * (lane >> 2), h = lane & 3;
+    // sources: the four states of each target cell (this wave's targets are w, w + FLM_DC_WAVES, ...)
+    if (w < FLM_DC_WAVES && lane < 4 * (32 / FLM_DC_WAVES)) {
+      const int j = w + FLM_DC_WAVES * (lane >> 2), h = lane & 3;
       if (j < nslot) {
         const int tcell = slot_target[(size_t)e * A + base_slot + j];
         if (tcell >= 0 && tcell < HW) {
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(FLM_DC_THREADS) void distance_chain_kernel(
     wave_sync();
     // list sizes live in (wave-uniform) registers; appends are placed by ballot ranks, so the only LDS
     // atomics left are the dirty-set updates, which rarely meet on one address
-    int n_c = min(cnt[0], FLM_DC_LIST);
+    int n_c = w < FLM_DC_WAVES ? min(cnt[0], FLM_DC_LIST) : 0;
     for (int round = 0; round < 65536; round++) {
       if (n_c == 0) break;
       // phase 1: predecessors of the changed pairs become dirty
@@ -463,7 +466,7 @@ extern "C" int flm_distance_chains(const uint16_t* root, const uint16_t* steps, 
     return FLM_E_ARG;
   if (ldsAnch > 2047) return FLM_E_ARG;   // anchors are packed in 11 bits on the work lists
   if (capCells & 1) return FLM_E_ARG;     // 16-byte row stores
-  size_t lds = (size_t)ldsAnch * (16 + 2 * FLM_DA_ROW + 4 + 4 + 8) + 16 + (FLM_DC_THREADS / 64) * 2 * FLM_DC_LIST * 2;
+  size_t lds = (size_t)ldsAnch * (16 + 2 * FLM_DA_ROW + 4 + 4 + 8) + 16 + FLM_DC_WAVES * 2 * FLM_DC_LIST * 2;
   if (lds > 160 * 1024 - 512) return FLM_E_ARG;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(flm::distance_chain_kernel),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
