@@ -33,7 +33,8 @@ def obs_to_f32(obs_u8, Rp, T1, plane_stride, out=None):
 
 
 class DQNPolicy:
-    """policy(rollout, info) for RolloutBatch.step; keeps what the replay memory needs in `last`."""
+    """policy(rollout, info) for RolloutBatch.step; keeps what the replay memory needs in `last`: a list of
+    (agents e*A+a, their observations as shown to the network, the actions chosen) per group of agents."""
 
     def __init__(self, agent, eps=0.0, seed=0, chunk_bytes=2 << 30):
         self.agent = agent
@@ -109,10 +110,8 @@ class DQNPolicy:
                 reqs.append(req2[keep])
                 obss.append(obs2[sel[keep]])
                 acts.append(a2[keep])
-        if reqs:
-            self.last = dict(req=torch.cat(reqs), obs=torch.cat(obss), action=torch.cat(acts))
-        else:
-            self.last = None
+        # one entry per group of consulting agents (departing, in front of a switch): (agents, observations, actions)
+        self.last = list(zip(reqs, obss, acts)) if reqs else None
         return net, best
 
 
@@ -139,12 +138,13 @@ class DeviceReplay:
         if n > self.capacity:
             state, action, reward, next_state, done = (x[-self.capacity:] for x in (state, action, reward, next_state, done))
             n = self.capacity
-        idx = (torch.arange(n, device=self.state.device) + self.head) % self.capacity
-        self.state[idx] = state
-        self.next_state[idx] = next_state
-        self.action[idx] = action.to(torch.int64)
-        self.reward[idx] = reward.to(torch.float32)
-        self.done[idx] = done.to(torch.float32)
+        # the ring is filled with at most two contiguous copies
+        first = min(n, self.capacity - self.head)
+        for dst, src in ((self.state, state), (self.next_state, next_state), (self.action, action.to(torch.int64)),
+                         (self.reward, reward.to(torch.float32)), (self.done, done.to(torch.float32))):
+            dst[self.head:self.head + first].copy_(src[:first])
+            if n > first:
+                dst[:n - first].copy_(src[first:])
         self.head = (self.head + n) % self.capacity
         self.size = min(self.capacity, self.size + n)
 
@@ -189,22 +189,25 @@ class BatchedTrainer:
         last = self.policy.last
         n_new = 0
         if train and last is not None:
-            req = last["req"].long()
-            # the observation after the step: the agent's own plane against everybody's (src/main.py:277)
-            next_obs = ro.consult_observations(last["req"].contiguous())
-            reward = ro.reward.view(-1)[req]
-            done = ro.done.view(-1)[req]
-            net_out = ro.net.view(-1)[req]                 # the decision after the crash checks (src/main.py:180, 225)
-            self.replay.add(last["obs"], net_out, reward, next_obs, done)
-            n_new = req.numel()
-            if self.crash_penalty:                         # src/main.py:271-273, for the agents that consulted this step
-                cr = ro.crash.view(-1)[req] != 0
-                k = int(cr.sum().item())
-                if k:
-                    o = last["obs"][cr]
-                    self.replay.add(o, torch.ones(k, dtype=torch.int64, device=ro.device),
-                                    torch.full((k,), -100.0, device=ro.device), o, torch.ones(k, device=ro.device))
-                    n_new += k
+            for req32, obs, _ in last:
+                req = req32.long()
+                if req.numel() == 0:
+                    continue
+                # the observation after the step: the agent's own plane against everybody's (src/main.py:277)
+                next_obs = ro.consult_observations(req32.contiguous())
+                reward = ro.reward.view(-1)[req]
+                done = ro.done.view(-1)[req]
+                net_out = ro.net.view(-1)[req]             # the decision after the crash checks (src/main.py:180, 225)
+                self.replay.add(obs, net_out, reward, next_obs, done)
+                n_new += req.numel()
+                if self.crash_penalty:                     # src/main.py:271-273, for the agents that consulted this step
+                    cr = ro.crash.view(-1)[req] != 0
+                    k = int(cr.sum().item())
+                    if k:
+                        o = obs[cr]
+                        self.replay.add(o, torch.ones(k, dtype=torch.int64, device=ro.device),
+                                        torch.full((k,), -100.0, device=ro.device), o, torch.ones(k, device=ro.device))
+                        n_new += k
             self.n_transitions += n_new
             # src/agent.py:57-67: one learn step per update_every stored transitions, once the memory is large enough
             due = (self.t_step + n_new) // self.agent.args.update_every
