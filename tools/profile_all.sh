@@ -1,5 +1,5 @@
 #!/bin/bash
-# Collect the round's rocprofv3 evidence on one GPU: kernel statistics of the bench step, the DQN kernels and
+# Collect rocprofv3 evidence on one GPU: kernel statistics of the bench step, the DQN kernels and
 # the rollout, the MFMA-busy counters of the DQN kernels, and HBM traffic counters of the bench step.
 # Every pass is its own run with its own time limit; the script stops at the first failure.
 set -e

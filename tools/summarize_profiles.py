@@ -1,5 +1,5 @@
-"""Turn the rocprofv3 outputs of tools/profile_round.sh (gpurun_out/prof_c) into the committed summaries
-under profiles/ (python tools/summarize_profiles.py r01_c)."""
+"""Turn the rocprofv3 outputs of tools/profile_all.sh (gpurun_out/prof_c) into the committed summaries
+under profiles/ (python tools/summarize_profiles.py <tag>)."""
 import csv
 import json
 import os
@@ -9,7 +9,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_c")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01_c"
+tag = sys.argv[1] if len(sys.argv) > 1 else "profile"
 OUT = os.path.join(ROOT, "profiles")
 
 
