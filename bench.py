@@ -120,7 +120,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    device = torch.device("cuda", local_rank if world > 1 else 0)
+    device = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()) if world > 1 else 0)
     torch.cuda.set_device(device)
 
     import flatland_marl_amd as fm
@@ -193,6 +193,7 @@ def main():
               for _ in range(args.steps)]
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()

