@@ -112,7 +112,8 @@ def main():
     ap.add_argument("--chunks", type=int, default=1, help="split the batch into this many sub-batches")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the sub-batches are spread over")
     ap.add_argument("--obs-serial", type=int, default=1,
-                    help="1: observation kernels run one after the other on the main stream after the other stages")
+                    help="1: observation kernels run one after the other on the main stream after the other stages; "
+                         "2: pipelined, the other stages of the next sub-batch run on a side stream meanwhile")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rollout", action="store_true", help="skip the env-steps/s sample of the batched rollout")
     args = ap.parse_args()
@@ -160,7 +161,36 @@ def main():
     batch = batches[0]
     T1 = batch.T1
 
+    ready = [torch.cuda.Event() for _ in batches]
+    consumed = [None for _ in batches]
+
+    def step_pipelined(ev=None):
+        # side stream: graph .. columns of sub-batch i+1 while the main stream writes the observations of sub-batch i
+        side = streams[0]
+        for ci, b in enumerate(batches):
+            keep, b.stream = b.stream, side
+            with torch.cuda.stream(side):
+                if consumed[ci] is not None:
+                    side.wait_event(consumed[ci])       # the previous step's observation kernel has read the columns
+                b.build_graph(sync=False)
+                b.compute_distances()
+                b.shortest_paths()
+                b.columns(shift=1)
+                ready[ci].record(side)
+            main_stream.wait_event(ready[ci])
+            b.stream = main_stream
+            if ev is not None:
+                ev[ci][0].record(main_stream)
+            b.observations_fused()
+            if ev is not None:
+                ev[ci][1].record(main_stream)
+            consumed[ci] = torch.cuda.Event()
+            consumed[ci].record(main_stream)
+            b.stream = keep
+
     def step(ev=None):
+        if args.obs_serial == 2:
+            return step_pipelined(ev)
         for st in streams:
             st.wait_stream(main_stream)
         for ci, b in enumerate(batches):
