@@ -113,7 +113,7 @@ __device__ __forceinline__ void place_tile(float (*S)[GBM + BPAD + APAD], int ti
 }
 
 template <bool A_KC, bool B_KC, int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float As[GBK][GBM + BPAD + APAD];
   __shared__ __attribute__((aligned(16))) float Bs[GBK][GBN + BPAD + APAD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
