@@ -50,18 +50,17 @@ __device__ __forceinline__ unsigned long long lanemask_lt() {
   return (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 }
 
-// Exclusive prefix of a per-thread flag over a 256-thread block, plus the block total.
-// scratch: 4 ints of LDS; contains two barriers.
-__device__ __forceinline__ int block_flag_scan256(bool flag, int* scratch, int* total) {
-  unsigned long long m = __ballot(flag);
-  int w = threadIdx.x >> 6;
-  int within = __popcll(m & lanemask_lt());
+// Exclusive prefix of a per-thread flag over the workgroup (up to 1024 threads), plus the workgroup total.
+// scratch: 16 ints of LDS; contains two barriers.
+__device__ __forceinline__ int block_flag_scan(bool flag, int* scratch, int* total) {
+  const unsigned long long m = __ballot(flag);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  const int within = __popcll(m & lanemask_lt());
   if ((threadIdx.x & 63) == 0) scratch[w] = __popcll(m);
   __syncthreads();
   int base = 0, tot = 0;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    int v = scratch[i];
+  for (int i = 0; i < nw; i++) {
+    const int v = scratch[i];
     if (i < w) base += v;
     tot += v;
   }
@@ -70,9 +69,9 @@ __device__ __forceinline__ int block_flag_scan256(bool flag, int* scratch, int* 
   return base + within;
 }
 
-// Exclusive prefix sum of a per-thread int over a 256-thread block, plus the block total.
-__device__ __forceinline__ int block_int_scan256(int v, int* scratch, int* total) {
-  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+// Exclusive prefix sum of a per-thread int over the workgroup (up to 1024 threads), plus the workgroup total.
+__device__ __forceinline__ int block_int_scan(int v, int* scratch, int* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   int inc = v;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -82,9 +81,8 @@ __device__ __forceinline__ int block_int_scan256(int v, int* scratch, int* total
   if (lane == 63) scratch[w] = inc;
   __syncthreads();
   int base = 0, tot = 0;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    int s = scratch[i];
+  for (int i = 0; i < nw; i++) {
+    const int s = scratch[i];
     if (i < w) base += s;
     tot += s;
   }

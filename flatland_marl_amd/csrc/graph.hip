@@ -1,4 +1,4 @@
-// Switch-graph construction, one 256-thread workgroup per environment.
+// Switch-graph construction, one 1024-thread workgroup per environment.
 //
 // The numbering the sequential definition produces (src/rail_observations.py:410-510 of the
 // reference) is reproduced without a sequential pass:
@@ -58,7 +58,7 @@ __device__ Walk walk_rail(const uint16_t* grid, const NodeT* node_id, int H, int
 // LDS_GRID: the transition codes and the node numbers of the environment are staged in LDS (2 + 2 bytes per
 // cell), so that the rail walks, chains of dependent look-ups, run at LDS latency.
 template <bool LDS_GRID>
-__global__ __launch_bounds__(256) void graph_build_kernel(
+__global__ __launch_bounds__(1024) void graph_build_kernel(
     const uint16_t* __restrict__ grid_all, int H, int W, int capN, int capR, int capC, int32_t* __restrict__ node_id_all,
     int32_t* __restrict__ node_cell_all, int32_t* __restrict__ edge_info_all, int32_t* __restrict__ edge_cell_off_all,
     int32_t* __restrict__ edge_cells_all, int32_t* __restrict__ cell_rail_all, int32_t* __restrict__ counts_all) {
@@ -74,20 +74,20 @@ __global__ __launch_bounds__(256) void graph_build_kernel(
   int32_t* cell_rail = cell_rail_all + (size_t)e * HW;
   int32_t* counts = counts_all + (size_t)e * 4;
 
-  int* scratch = lds;                 // 8 ints
-  int* p_end = lds + 8;               // [4*capN]
+  int* scratch = lds;                 // 16 ints
+  int* p_end = lds + 16;              // [4*capN]
   int* p_len = p_end + 4 * capN;      // [4*capN]
   int* p_first = p_len + 4 * capN;    // [4*capN]
   int* conn = p_first + 4 * capN;     // [capN] connection mask per node
   uint16_t* l_code = reinterpret_cast<uint16_t*>(conn + capN);   // [HW] when LDS_GRID
   int16_t* l_node = reinterpret_cast<int16_t*>(l_code + HW);     // [HW] when LDS_GRID
   const uint16_t* grid = LDS_GRID ? l_code : grid_g;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, T = blockDim.x;
   int err = 0;
 
   // ---- nodes: row-major numbering
   int n_nodes = 0;
-  for (int base = 0; base < HW; base += 256) {
+  for (int base = 0; base < HW; base += T) {
     int cell = base + tid;
     bool is_node = false;
     int mask = 0;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void graph_build_kernel(
       cell_rail[cell] = -1;
     }
     int tot;
-    int id = n_nodes + block_flag_scan256(is_node, scratch, &tot);
+    int id = n_nodes + block_flag_scan(is_node, scratch, &tot);
     if (cell < HW) {
       node_id[cell] = (is_node && id < capN) ? id : -1;
       if (LDS_GRID) l_node[cell] = (int16_t)((is_node && id < capN) ? id : -1);
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void graph_build_kernel(
 
   // ---- every connected port walks to the next node
   const int n_ports = n_nodes * 4;
-  for (int p = tid; p < n_ports; p += 256) {
+  for (int p = tid; p < n_ports; p += T) {
     p_first[p] = 0x7FFFFFFF;
     p_end[p] = -1;
     p_len[p] = 0;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void graph_build_kernel(
     }
   }
   __syncthreads();
-  for (int p = tid; p < n_ports; p += 256) {
+  for (int p = tid; p < n_ports; p += T) {
     int q = p_end[p];
     if (q >= 0) {
       bool q_done_before = ((conn[q >> 2] >> (q & 3)) & 1) && q <= p;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void graph_build_kernel(
 
   // ---- edge ids = prefix count of creating ports; cell offsets = prefix sum of their lengths
   int n_edges = 0, n_cells = 0;
-  for (int base = 0; base < n_ports; base += 256) {
+  for (int base = 0; base < n_ports; base += T) {
     int p = base + tid;
     bool creates = false;
     int len = 0;
@@ -165,8 +165,8 @@ __global__ __launch_bounds__(256) void graph_build_kernel(
       len = creates ? p_len[p] : 0;
     }
     int tot_e, tot_c;
-    int id = n_edges + block_flag_scan256(creates, scratch, &tot_e);
-    int off = n_cells + block_int_scan256(len, scratch, &tot_c);
+    int id = n_edges + block_flag_scan(creates, scratch, &tot_e);
+    int off = n_cells + block_int_scan(len, scratch, &tot_c);
     if (creates && id < capR) {
       int q = p_end[p];
       int32_t* ei = edge_info + id * 5;
@@ -266,7 +266,7 @@ extern "C" int flm_graph_build(const uint16_t* grid, int E, int H, int W, int ca
   if (!grid || !node_id || !node_cell || !edge_info || !edge_cell_off || !edge_cells || !cell_rail || !counts)
     return FLM_E_ARG;
   if (E <= 0 || H <= 0 || W <= 0 || capN <= 0 || capN > FLM_MAX_NODES || capR <= 0 || capC <= 0) return FLM_E_ARG;
-  const size_t lds_ports = sizeof(int) * (8 + (size_t)capN * 13);
+  const size_t lds_ports = sizeof(int) * (16 + (size_t)capN * 13);
   const size_t lds_grid = lds_ports + 4 * (size_t)H * W;
   // stage the grid in LDS when two workgroups still fit a CU (80 KB each)
   const bool staged = lds_grid <= 80 * 1024;
@@ -276,10 +276,10 @@ extern "C" int flm_graph_build(const uint16_t* grid, int E, int H, int W, int ca
   if (lds > 160 * 1024 - 512) return FLM_E_ARG;
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return FLM_E_LAUNCH;
   if (staged)
-    hipLaunchKernelGGL(flm::graph_build_kernel<true>, dim3(E), dim3(256), lds, (hipStream_t)stream, grid, H, W, capN, capR,
+    hipLaunchKernelGGL(flm::graph_build_kernel<true>, dim3(E), dim3(1024), lds, (hipStream_t)stream, grid, H, W, capN, capR,
                        capC, node_id, node_cell, edge_info, edge_cell_off, edge_cells, cell_rail, counts);
   else
-    hipLaunchKernelGGL(flm::graph_build_kernel<false>, dim3(E), dim3(256), lds, (hipStream_t)stream, grid, H, W, capN, capR,
+    hipLaunchKernelGGL(flm::graph_build_kernel<false>, dim3(E), dim3(1024), lds, (hipStream_t)stream, grid, H, W, capN, capR,
                        capC, node_id, node_cell, edge_info, edge_cell_off, edge_cells, cell_rail, counts);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
