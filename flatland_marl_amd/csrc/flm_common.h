@@ -106,6 +106,31 @@ __device__ __forceinline__ int greedy_path(const uint16_t* __restrict__ grid, co
   int n = 0, depth = 0;
   int s = -1;                 // compact state number of (cell, h) while it is known
   bool reach = false;         // the current state is known to reach the target, best_d is its distance
+  // elements are collected four at a time and stored as 16 bytes when the output rows are 16-byte aligned
+  const bool vec = ((reinterpret_cast<size_t>(pc) | reinterpret_cast<size_t>(pm)) & 15) == 0;
+  int bc[4] = {0, 0, 0, 0};
+  unsigned bm[4] = {0, 0, 0, 0};
+  auto emit = [&](int c, unsigned m) {
+    if (vec) {
+      bc[n & 3] = c;
+      bm[n & 3] = m;
+      if ((n & 3) == 3 && n < cap) {
+        *reinterpret_cast<int4*>(pc + n - 3) = make_int4(bc[0], bc[1], bc[2], bc[3]);
+        *reinterpret_cast<uint4*>(pm + n - 3) = make_uint4(bm[0], bm[1], bm[2], bm[3]);
+      }
+    } else if (n < cap) {
+      pc[n] = c;
+      pm[n] = m;
+    }
+    n++;
+  };
+  auto flush = [&]() {     // the last, partial group of four
+    if (vec)
+      for (int i = n & ~3; i < n && i < cap; i++) {
+        pc[i] = bc[i & 3];
+        pm[i] = bm[i & 3];
+      }
+  };
   if (succ && cell >= 0 && cell < H * W) {
     const int idx = cell_idx[cell];
     if (idx >= 0) s = idx * 4 + h;
@@ -121,11 +146,7 @@ __device__ __forceinline__ int greedy_path(const uint16_t* __restrict__ grid, co
           reach = true;
         }
         const int nd = (int)(nx & 3u);
-        if (n < cap) {
-          pc[n] = cell;
-          pm[n] = (unsigned)h | (2u << 8) | ((unsigned)nd << 16);
-        }
-        n++;
+        emit(cell, (unsigned)h | (2u << 8) | ((unsigned)nd << 16));
         depth++;
         cell += dr(nd) * W + dc(nd);
         h = nd;
@@ -151,24 +172,15 @@ __device__ __forceinline__ int greedy_path(const uint16_t* __restrict__ grid, co
       }
     }
     if (best < 0) return -1;
-    if (n < cap) {
-      pc[n] = cell;
-      pm[n] = (unsigned)h | ((unsigned)act[best] << 8) | ((unsigned)nd[best] << 16);
-    }
-    n++;
+    emit(cell, (unsigned)h | ((unsigned)act[best] << 8) | ((unsigned)nd[best] << 16));
     depth++;
     cell = (r + dr(nd[best])) * W + c + dc(nd[best]);
     h = nd[best];
     if (succ) s = best_idx * 4 + h;
     reach = true;
   }
-  if (depth < max_depth) {  // closing element: stop on the cell reached
-    if (n < cap) {
-      pc[n] = cell;
-      pm[n] = (unsigned)h | (4u << 8) | ((unsigned)h << 16);
-    }
-    n++;
-  }
+  if (depth < max_depth) emit(cell, (unsigned)h | (4u << 8) | ((unsigned)h << 16));   // closing element: stop on the cell reached
+  flush();
   return n;
 }
 
