@@ -79,13 +79,16 @@ def rollout_sample(device, steps=40):
     data = make_batch(load_fixtures(names), E, A, seed=0)
     b = fm.ObservationBatch(data["grid"], data["start"], data["direction"], data["target"], data["speed"], depth,
                             max_rails=100, device=device)
-    ro = RolloutBatch(b, data["speed"], data["direction"], max_alt_depth=max(200, depth + 1) + 2).reset()   # episodes of <= 200 steps (src/main.py:93)
+    # episodes of <= 200 steps (src/main.py:93); malfunction process with the script's defaults (src/main.py:373-375)
+    malf = dict(rate=2000, min_duration=0, max_duration=0, seed=0)
+    ro = RolloutBatch(b, data["speed"], data["direction"], max_alt_depth=max(200, depth + 1) + 2, malfunction=malf).reset()
     a = types.SimpleNamespace(prediction_depth=depth, lr=5e-5, buffer_size=20000, batch_size=512, update_every=10,
                               gamma=0.99, tau=1e-3)
     agent = DQNAgent(a, action_space=2, bitmap_height=3 * b.Rp)
     tr = BatchedTrainer(ro, agent, start_eps=0.1, max_learns_per_step=4)
     out = {"unit": "env-steps/s", "config": {"workload": "cfg2: " + desc, "envs": E, "agents": A, "rails_padded": int(b.Rp),
-                                             "depth": depth, "steps_timed": steps, "eps": 0.1}}
+                                             "depth": depth, "steps_timed": steps, "eps": 0.1,
+                                             "speeds": "1, 1/2, 1/3, 1/4", "malfunction": malf}}
     for key, train in (("act_only", False), ("act_and_learn", True)):
         ro.reset()
         for _ in range(3):

@@ -17,6 +17,7 @@ ABI_VERSION = 1
 
 _p = C.c_void_p
 _i = C.c_int
+_u32 = C.c_uint32
 
 _SIGNATURES = {
     "flm_abi_version": [],
@@ -36,7 +37,7 @@ _SIGNATURES = {
     "flm_observations_req_columns": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "flm_rollout_classify": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "flm_rollout_apply": [_p] * 18 + [_i] * 6 + [_p, _p, _p, _p],
-    "flm_env_step": [_p] * 13 + [_i] * 4 + [_p, _p, _p, _p],
+    "flm_env_step": [_p] * 13 + [_i] * 4 + [_p] * 6 + [_u32, _i, _i, _i, _p],
     "flm_altpaths": [_p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     "flm_check_crash": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     "flm_update_bitmaps": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],

@@ -339,18 +339,36 @@ __global__ __launch_bounds__(64) void rollout_apply_kernel(
   }
 }
 
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+
 // One environment step for every environment (agents in handle order, one wave per environment): a train
 // leaves its start cell on a move action if that cell is free; at a cell boundary the action is
 // interpreted (an impossible left/right falls back to forward, an impossible move stops the train); a
 // moving train advances by `speed` per step and enters the next cell when the fraction reaches 1 and the
-// cell is free; a train that reaches its target leaves the grid.  No malfunctions.
+// cell is free; a train that reaches its target leaves the grid.  Reward: -speed per step for a train that
+// has not arrived, 0 on arrival and afterwards, +1 to every agent in the step in which the last one arrives.
+//
+// Malfunction process (malf_all != nullptr; flatland's malfunction_from_params): before the step every agent
+// that is not broken breaks with probability threshold / 2^32 for min + draw % (max - min + 1) + 1 steps and
+// remembers whether it was moving; a broken train on the grid ignores its action and stays where it is;
+// after the agent's step the counter goes down by one and `moving` is restored when it reaches zero.  The
+// draws are a counter hash of (environment seed, step, agent), not flatland's MT19937 stream.
 __global__ __launch_bounds__(64) void env_step_kernel(
     const uint16_t* __restrict__ grid_all, const int32_t* __restrict__ action_all, const int32_t* __restrict__ init_all,
     const int32_t* __restrict__ init_dir_all, const int32_t* __restrict__ target_all,
     const double* __restrict__ speed_all, int32_t* __restrict__ status_all, int32_t* __restrict__ pos_all,
     int32_t* __restrict__ dir_all, int32_t* __restrict__ moving_all, double* __restrict__ frac_all,
     int32_t* __restrict__ exit_action_all, int32_t* __restrict__ done_all, int A, int H, int W,
-    double* __restrict__ reward_all, int32_t* __restrict__ action_required, int32_t* __restrict__ all_done) {
+    double* __restrict__ reward_all, int32_t* __restrict__ action_required, int32_t* __restrict__ all_done,
+    int32_t* __restrict__ malf_all, int32_t* __restrict__ malf_moving_all, const uint32_t* __restrict__ env_seed,
+    uint32_t malf_threshold, int malf_min, int malf_span, int step_index) {
   extern __shared__ int s_pos[];
   const int e = blockIdx.x, lane = threadIdx.x;
   const size_t base = (size_t)e * A;
@@ -388,26 +406,34 @@ __global__ __launch_bounds__(64) void env_step_kernel(
     *np_out = inside ? r * W + c : -1;
     return cv && tv != 0;
   };
+  const uint32_t seed = malf_all ? env_seed[e] : 0u;
+  const bool already_over = all_done[e] != 0;
   int n_done = 0;
   for (int i = 0; i < A; i++) {
     const size_t g = base + i;
     int status = status_all[g];
     double reward = 0.0;
     const double speed = speed_all[g];
-    if (status >= 2) {
-      n_done += done_all[g] ? 1 : 0;
-      if (lane == 0) {
-        reward_all[g] = 0.0;
-        action_required[g] = 0;
-      }
-      continue;
-    }
-    int action = action_all[g];
     int pos = s_pos[i], dir = dir_all[g], moving = moving_all[g];
     double frac = frac_all[g];
     int exit_action = exit_action_all[g];
     int done = done_all[g];
-    if (status == 0) {
+    int malf = 0, malf_moving = 0;
+    if (malf_all) {
+      malf = malf_all[g];
+      malf_moving = malf_moving_all[g];
+      if (malf < 1) {
+        const uint32_t h1 = fmix32(seed ^ fmix32((uint32_t)step_index * 0x9E3779B1u + (uint32_t)i * 0x85EBCA77u + 1u));
+        if (h1 < malf_threshold) {
+          malf = malf_min + (int)(fmix32(h1 ^ 0x27D4EB2Fu) % (uint32_t)malf_span) + 1;
+          malf_moving = moving;
+        }
+      }
+    }
+    if (status >= 2) {
+      // finished: nothing moves
+    } else if (status == 0) {
+      const int action = action_all[g];
       if (action >= 1 && action <= 3 && cell_free(init_all[g])) {
         status = 1;
         pos = init_all[g];
@@ -415,7 +441,10 @@ __global__ __launch_bounds__(64) void env_step_kernel(
         moving = 1;
       }
       reward = -speed;
+    } else if (malf > 0) {
+      reward = -speed;
     } else {
+      int action = action_all[g];
       if (fabs(frac) < 1e-9) {
         if (action == 0 && moving) action = 2;
         if (action == 4 && moving) moving = 0;
@@ -454,6 +483,10 @@ __global__ __launch_bounds__(64) void env_step_kernel(
       }
       reward = done ? 0.0 : -speed;
     }
+    if (malf >= 1) {
+      malf--;
+      if (malf == 0) moving = malf_moving;
+    }
     n_done += done ? 1 : 0;
     __syncthreads();
     if (lane == 0) {
@@ -467,10 +500,18 @@ __global__ __launch_bounds__(64) void env_step_kernel(
       done_all[g] = done;
       reward_all[g] = reward;
       action_required[g] = (status == 0 || (status == 1 && fabs(frac) < 1e-9)) ? 1 : 0;
+      if (malf_all) {
+        malf_all[g] = malf;
+        malf_moving_all[g] = malf_moving;
+      }
     }
     __syncthreads();
   }
+  __syncthreads();
   if (lane == 0) all_done[e] = n_done == A ? 1 : 0;
+  // the step that finishes the last agent pays the global reward to every agent
+  if (n_done == A && !already_over)
+    for (int o = lane; o < A; o += 64) reward_all[base + o] = 1.0;
 }
 
 }  // namespace flm
@@ -514,14 +555,20 @@ extern "C" int flm_env_step(const uint16_t* grid, const int32_t* action, const i
                             const int32_t* init_dir, const int32_t* target_cell, const double* speed, int32_t* status,
                             int32_t* pos_cell, int32_t* direction, int32_t* moving, double* fraction,
                             int32_t* exit_action, int32_t* done, int E, int A, int H, int W, double* reward,
-                            int32_t* action_required, int32_t* all_done, void* stream) {
+                            int32_t* action_required, int32_t* all_done, int32_t* malfunction,
+                            int32_t* malfunction_moving, const uint32_t* env_seed, uint32_t malfunction_threshold,
+                            int min_duration, int max_duration, int step_index, void* stream) {
   if (!grid || !action || !init_cell || !init_dir || !target_cell || !speed || !status || !pos_cell || !direction ||
       !moving || !fraction || !exit_action || !done || !reward || !action_required || !all_done)
     return FLM_E_ARG;
   if (E <= 0 || A <= 0 || A > 8192 || H <= 0 || W <= 0) return FLM_E_ARG;
+  if (malfunction && (!malfunction_moving || !env_seed || min_duration < 0 || max_duration < min_duration ||
+                      step_index < 0))
+    return FLM_E_ARG;
   hipLaunchKernelGGL(flm::env_step_kernel, dim3(E), dim3(64), sizeof(int) * (size_t)A, (hipStream_t)stream, grid, action,
                      init_cell, init_dir, target_cell, speed, status, pos_cell, direction, moving, fraction, exit_action,
-                     done, A, H, W, reward, action_required, all_done);
+                     done, A, H, W, reward, action_required, all_done, malfunction, malfunction_moving, env_seed,
+                     malfunction_threshold, min_duration, max_duration - min_duration + 1, step_index);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }

@@ -9,7 +9,8 @@ loop (shift, delay, crash checks) moves or reads whole columns.  One step is
     policy     -> stop/go and the chosen alternative (the network of src/main.py:168-172, 197-208, or any
                   other callable; it may ask for the observations of the consulting agents)
     apply      -> the sequential per-agent bookkeeping, one wave per environment
-    env step   -> the environment advances (stand-in for flatland's RailEnv.step, no malfunctions)
+    env step   -> the environment advances (stand-in for flatland's RailEnv.step, with its malfunction
+                  process when asked for)
 
 Dense observations are only produced for the agents that consult the policy.
 """
@@ -23,7 +24,11 @@ MAX_REQ = 65535      # requests per launch of the request kernels
 
 
 class RolloutBatch:
-    def __init__(self, batch: ObservationBatch, speed, initial_direction=None, cap_alt=8, max_alt_depth=500):
+    def __init__(self, batch: ObservationBatch, speed, initial_direction=None, cap_alt=8, max_alt_depth=500,
+                 malfunction=None):
+        """malfunction = dict(rate, min_duration, max_duration, seed[, env_seeds]): the parameters of the
+        malfunction_from_params generator of src/main.py:72-77 (rate 0 = never; the script's defaults are
+        2000, 0, 0).  Environment e draws from the seed env_seeds[e] (default: a hash of seed and e)."""
         self.b = b = batch
         E, A, dev = b.E, b.A, b.device
         self.E, self.A, self.device = E, A, dev
@@ -62,6 +67,24 @@ class RolloutBatch:
         self._dummy_i16 = torch.zeros((1,), dtype=torch.int16, device=dev)
         self.cols = None
         self.t = 0
+        self.malfunction = self.malfunction_moving = self.env_seed = None
+        self.malf_threshold, self.malf_min, self.malf_max = 0, 0, 0
+        if malfunction and malfunction.get("rate", 0) > 0:
+            self.malf_threshold = min(0xFFFFFFFF, int((1.0 - np.exp(-1.0 / malfunction["rate"])) * 4294967296.0))
+            self.malf_min, self.malf_max = int(malfunction["min_duration"]), int(malfunction["max_duration"])
+            seeds = malfunction.get("env_seeds")
+            if seeds is None:
+                x = (np.arange(E, dtype=np.uint64) * np.uint64(0x9E3779B1) + np.uint64(int(malfunction.get("seed", 0)))
+                     ) & np.uint64(0xFFFFFFFF)
+                x ^= x >> np.uint64(16)
+                x = (x * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+                x ^= x >> np.uint64(13)
+                seeds = x
+            seeds = np.asarray(seeds, np.uint64).reshape(E).astype(np.int64)
+            # uint32 bit patterns in an int32 tensor
+            self.env_seed = torch.as_tensor(np.where(seeds >= 2 ** 31, seeds - 2 ** 32, seeds).astype(np.int32), device=dev)
+            self.malfunction = torch.zeros((E, A), **i32)
+            self.malfunction_moving = torch.zeros((E, A), **i32)
 
     @property
     def stream(self):
@@ -81,6 +104,9 @@ class RolloutBatch:
         self.all_done.zero_()
         self.action_required.fill_(1)
         self.agent_err.zero_()
+        if self.malfunction is not None:
+            self.malfunction.zero_()
+            self.malfunction_moving.zero_()
         b.status.zero_()
         b.pos_cell.copy_(b.start_cell)
         b.direction.copy_(self.init_dir)
@@ -171,7 +197,11 @@ class RolloutBatch:
         call("flm_env_step", ptr(b.grid), ptr(self.action), ptr(b.start_cell), ptr(self.init_dir), ptr(b.target_cell),
              ptr(self.speed), ptr(self.status), ptr(self.pos), ptr(self.heading), ptr(self.moving), ptr(self.fraction),
              ptr(self.exit_action), ptr(self.done), self.E, self.A, b.H, b.W, ptr(self.reward),
-             ptr(self.action_required), ptr(self.all_done), self.stream)
+             ptr(self.action_required), ptr(self.all_done),
+             ptr(self.malfunction) if self.malfunction is not None else None,
+             ptr(self.malfunction_moving) if self.malfunction is not None else None,
+             ptr(self.env_seed) if self.malfunction is not None else None,
+             self.malf_threshold, self.malf_min, self.malf_max, self.t, self.stream)
 
     # ------------------------------------------------------------------ one step
     def step(self, policy):

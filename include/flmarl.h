@@ -257,13 +257,22 @@ int flm_rollout_apply(int16_t* cols, const int32_t* status, const int32_t* tpc, 
 
 /* flm_env_step: one environment step for every environment, agents in handle order.  Stands in for
  * flatland RailEnv.step as called at src/main.py:252 (third-party, absent: restated from its published
- * rules without malfunctions; the same rules as the stand-in the golden traces were recorded with).
+ * rules; the same rules as the stand-in the golden traces were recorded with).
  *   status/pos_cell/direction/moving/fraction/exit_action/done [E,A] are updated in place (fraction,
- *   speed, reward are double); reward [E,A], action_required [E,A], all_done [E] out. */
+ *   speed, reward are double); reward [E,A], action_required [E,A], all_done [E] out.
+ * Malfunction process (the malfunction_from_params generator handed to RailEnv at src/main.py:72-77):
+ *   malfunction [E,A] = steps an agent stays broken (in/out; NULL switches the process off and the
+ *   remaining malfunction arguments are ignored), malfunction_moving [E,A] = `moving` at the time of the
+ *   break, env_seed [E] one 32-bit seed per environment, malfunction_threshold = floor((1 - exp(-1/rate))
+ *   * 2^32), durations min_duration..max_duration (+1, as flatland draws them), step_index = number of
+ *   steps since reset.  The draws are a counter hash of (seed, step, agent), not flatland's MT19937
+ *   stream. */
 int flm_env_step(const uint16_t* grid, const int32_t* action, const int32_t* init_cell, const int32_t* init_dir,
                  const int32_t* target_cell, const double* speed, int32_t* status, int32_t* pos_cell,
                  int32_t* direction, int32_t* moving, double* fraction, int32_t* exit_action, int32_t* done, int E,
-                 int A, int H, int W, double* reward, int32_t* action_required, int32_t* all_done, void* stream);
+                 int A, int H, int W, double* reward, int32_t* action_required, int32_t* all_done,
+                 int32_t* malfunction, int32_t* malfunction_moving, const uint32_t* env_seed,
+                 uint32_t malfunction_threshold, int min_duration, int max_duration, int step_index, void* stream);
 
 /* ---- Dueling Double-DQN (fp32; matrix products on the fp32 MFMA) -------------------------------------
  * Replaces Dueling_DQN.forward, src/model.py:31-43, and the numeric part of DQNAgent.act / learn /

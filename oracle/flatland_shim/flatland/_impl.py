@@ -235,13 +235,45 @@ class EnvAgent:
         self.old_position = None
 
 
+def _fmix32(h):
+    h &= 0xFFFFFFFF
+    h ^= h >> 16
+    h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+    h ^= h >> 13
+    h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+    h ^= h >> 16
+    return h
+
+
+def malfunction_draws(seed, step, agent):
+    """Two 32-bit draws for (environment seed, step, agent): the first decides whether the agent breaks
+    (draw < threshold), the second how long.  flatland draws from the environment's MT19937 stream
+    (np_random.rand(), np_random.randint()); that stream depends on every earlier draw of the
+    environment and cannot be reproduced without flatland, so a counter hash stands in for it."""
+    h = _fmix32(seed ^ _fmix32(step * 0x9E3779B1 + agent * 0x85EBCA77 + 1))
+    return h, _fmix32(h ^ 0x27D4EB2F)
+
+
+def malfunction_threshold(rate):
+    """flatland's per-step break probability 1 - exp(-1/rate) as a 32-bit threshold (0 = never)."""
+    if rate <= 0:
+        return 0
+    return min(0xFFFFFFFF, int((1.0 - np.exp(-1.0 / rate)) * 4294967296.0))
+
+
 class RailEnv(Environment):
     """Holds a fixed map + agents; reset() drives the observation builder the way
     flatland's RailEnv.reset does (obs_builder.reset() then get_many(all handles)).
-    step() implements a deterministic no-malfunction stepper used only to create
-    rollout scenarios for golden traces (flatland's own stepper is unavailable)."""
+    step() implements a deterministic stepper used only to create rollout scenarios for golden
+    traces (flatland's own stepper is unavailable).  `malfunction` = dict(rate, min_duration,
+    max_duration, seed) switches on the malfunction process of flatland's malfunction_from_params
+    (an agent that is not broken breaks with probability 1 - exp(-1/rate) per step for
+    randint(min, max + 1) + 1 steps; a broken agent on the grid ignores its action and does not
+    move; the counter goes down by one after every step and `moving` is restored when it reaches 0)."""
 
-    def __init__(self, grid, agents, obs_builder_object=None):
+    def __init__(self, grid, agents, obs_builder_object=None, malfunction=None):
+        self.malfunction = malfunction
+        self._elapsed = 0
         self.rail = GridTransitionMap(grid)
         self.height, self.width = self.rail.height, self.rail.width
         self.agents = agents
@@ -253,11 +285,11 @@ class RailEnv(Environment):
             self.obs_builder.set_env(self)
 
     @classmethod
-    def from_fixture(cls, fx, obs_builder_object=None, num_agents=None):
+    def from_fixture(cls, fx, obs_builder_object=None, num_agents=None, malfunction=None):
         n = len(fx["handle"]) if num_agents is None else num_agents
         agents = [EnvAgent(fx["initial_position"][i], fx["initial_direction"][i], fx["direction"][i],
                            fx["target"][i], fx["speed"][i], i, fx["status"][i]) for i in range(n)]
-        return cls(fx["grid"], agents, obs_builder_object)
+        return cls(fx["grid"], agents, obs_builder_object, malfunction)
 
     def get_num_agents(self):
         return len(self.agents)
@@ -268,7 +300,7 @@ class RailEnv(Environment):
                                     (a.status == RailAgentStatus.ACTIVE and
                                      abs(a.speed_data["position_fraction"]) < 1e-9))
                                 for i, a in enumerate(self.agents)},
-            "malfunction": {i: 0 for i in range(len(self.agents))},
+            "malfunction": {i: a.malfunction_data["malfunction"] for i, a in enumerate(self.agents)},
             "speed": {i: a.speed_data["speed"] for i, a in enumerate(self.agents)},
             "status": {i: a.status for i, a in enumerate(self.agents)},
         }
@@ -281,6 +313,10 @@ class RailEnv(Environment):
             a.moving = False
             a.speed_data["position_fraction"] = 0.0
             a.speed_data["transition_action_on_cellexit"] = 0
+            a.malfunction_data["malfunction"] = 0
+            a.malfunction_data["nr_malfunctions"] = 0
+            a.malfunction_data.pop("moving_before_malfunction", None)
+        self._elapsed = 0
         self.dones = {i: False for i in range(len(self.agents))}
         self.dones["__all__"] = False
         self.distance_map.reset(self.agents, self.rail)
@@ -316,61 +352,93 @@ class RailEnv(Environment):
             transition_valid = bool(possible[new_direction])
         return new_cell_valid, new_direction, new_position, transition_valid
 
+    def _break_agent(self, i, agent):
+        m = self.malfunction
+        md = agent.malfunction_data
+        if not m or md["malfunction"] >= 1:
+            return
+        h1, h2 = malfunction_draws(int(m["seed"]), self._elapsed, i)
+        if h1 < malfunction_threshold(m["rate"]):
+            md["malfunction"] = int(m["min_duration"]) + h2 % (int(m["max_duration"]) - int(m["min_duration"]) + 1) + 1
+            md["moving_before_malfunction"] = agent.moving
+            md["nr_malfunctions"] += 1
+
+    def _fix_agent_after_malfunction(self, agent):
+        md = agent.malfunction_data
+        if md["malfunction"] < 1:
+            return
+        md["malfunction"] -= 1
+        if md["malfunction"] == 0 and "moving_before_malfunction" in md:
+            agent.moving = md["moving_before_malfunction"]
+
     def step(self, action_dict):
         rewards = {}
+        already_over = self.dones.get("__all__", False)
         for i, agent in enumerate(self.agents):
-            rewards[i] = 0
-            if agent.status in (RailAgentStatus.DONE, RailAgentStatus.DONE_REMOVED):
-                continue
-            action = RailEnvActions(int(action_dict.get(i, 0)))
-            sd = agent.speed_data
-            if agent.status == RailAgentStatus.READY_TO_DEPART:
-                if action in (RailEnvActions.MOVE_LEFT, RailEnvActions.MOVE_RIGHT,
-                              RailEnvActions.MOVE_FORWARD) and self.cell_free(agent.initial_position):
-                    agent.status = RailAgentStatus.ACTIVE
-                    agent.position = agent.initial_position
-                    agent.direction = agent.initial_direction
-                    agent.moving = True
-                rewards[i] = -sd["speed"]
-                continue
-            agent.old_direction, agent.old_position = agent.direction, agent.position
-            if abs(sd["position_fraction"]) < 1e-9:
-                if action == RailEnvActions.DO_NOTHING and agent.moving:
-                    action = RailEnvActions.MOVE_FORWARD
-                if action == RailEnvActions.STOP_MOVING and agent.moving:
-                    agent.moving = False
-                if not agent.moving and action not in (RailEnvActions.DO_NOTHING,
-                                                       RailEnvActions.STOP_MOVING):
-                    agent.moving = True
-                if agent.moving:
-                    valid = False
-                    if action not in (RailEnvActions.DO_NOTHING, RailEnvActions.STOP_MOVING):
-                        cv, nd, npos, tv = self._check_action(agent, action)
-                        if cv and tv:
-                            valid = True
-                        elif action in (RailEnvActions.MOVE_LEFT, RailEnvActions.MOVE_RIGHT):
-                            action = RailEnvActions.MOVE_FORWARD
-                            cv, nd, npos, tv = self._check_action(agent, action)
-                            valid = cv and tv
-                    if valid:
-                        sd["transition_action_on_cellexit"] = int(action)
-                    else:
-                        agent.moving = False
-            if agent.moving:
-                sd["position_fraction"] += sd["speed"]
-                if sd["position_fraction"] > 1.0 - 1e-9:
-                    cv, nd, npos, tv = self._check_action(
-                        agent, RailEnvActions(sd["transition_action_on_cellexit"]))
-                    if cv and tv and self.cell_free(npos):
-                        agent.position = npos
-                        agent.direction = nd
-                        sd["position_fraction"] = 0.0
-                if agent.position == agent.target:
-                    agent.status = RailAgentStatus.DONE_REMOVED
-                    agent.position = None
-                    agent.moving = False
-                    self.dones[i] = True
-            rewards[i] = -sd["speed"] if not self.dones[i] else 0
+            self._break_agent(i, agent)
+        for i, agent in enumerate(self.agents):
+            self._step_agent(i, agent, action_dict, rewards)
+            self._fix_agent_after_malfunction(agent)
+        self._elapsed += 1
         self.dones["__all__"] = all(self.dones[i] for i in range(len(self.agents)))
+        if self.dones["__all__"] and not already_over:
+            rewards = {i: 1.0 for i in range(len(self.agents))}       # flatland's global reward, paid once
         obs = self.obs_builder.get_many(list(range(len(self.agents))))
         return obs, rewards, dict(self.dones), self._info()
+
+    def _step_agent(self, i, agent, action_dict, rewards):
+        rewards[i] = 0
+        if agent.status in (RailAgentStatus.DONE, RailAgentStatus.DONE_REMOVED):
+            return
+        action = RailEnvActions(int(action_dict.get(i, 0)))
+        sd = agent.speed_data
+        if agent.status == RailAgentStatus.READY_TO_DEPART:
+            if action in (RailEnvActions.MOVE_LEFT, RailEnvActions.MOVE_RIGHT,
+                          RailEnvActions.MOVE_FORWARD) and self.cell_free(agent.initial_position):
+                agent.status = RailAgentStatus.ACTIVE
+                agent.position = agent.initial_position
+                agent.direction = agent.initial_direction
+                agent.moving = True
+            rewards[i] = -sd["speed"]
+            return
+        agent.old_direction, agent.old_position = agent.direction, agent.position
+        if agent.malfunction_data["malfunction"] > 0:
+            rewards[i] = -sd["speed"]
+            return
+        if abs(sd["position_fraction"]) < 1e-9:
+            if action == RailEnvActions.DO_NOTHING and agent.moving:
+                action = RailEnvActions.MOVE_FORWARD
+            if action == RailEnvActions.STOP_MOVING and agent.moving:
+                agent.moving = False
+            if not agent.moving and action not in (RailEnvActions.DO_NOTHING,
+                                                   RailEnvActions.STOP_MOVING):
+                agent.moving = True
+            if agent.moving:
+                valid = False
+                if action not in (RailEnvActions.DO_NOTHING, RailEnvActions.STOP_MOVING):
+                    cv, nd, npos, tv = self._check_action(agent, action)
+                    if cv and tv:
+                        valid = True
+                    elif action in (RailEnvActions.MOVE_LEFT, RailEnvActions.MOVE_RIGHT):
+                        action = RailEnvActions.MOVE_FORWARD
+                        cv, nd, npos, tv = self._check_action(agent, action)
+                        valid = cv and tv
+                if valid:
+                    sd["transition_action_on_cellexit"] = int(action)
+                else:
+                    agent.moving = False
+        if agent.moving:
+            sd["position_fraction"] += sd["speed"]
+            if sd["position_fraction"] > 1.0 - 1e-9:
+                cv, nd, npos, tv = self._check_action(
+                    agent, RailEnvActions(sd["transition_action_on_cellexit"]))
+                if cv and tv and self.cell_free(npos):
+                    agent.position = npos
+                    agent.direction = nd
+                    sd["position_fraction"] = 0.0
+            if agent.position == agent.target:
+                agent.status = RailAgentStatus.DONE_REMOVED
+                agent.position = None
+                agent.moving = False
+                self.dones[i] = True
+        rewards[i] = -sd["speed"] if not self.dones[i] else 0

@@ -35,7 +35,7 @@ def run_trace(env, obs_builder, preprocessor, n_steps, hash_obs=True):
     A = env.get_num_agents()
     maps, info = env.reset()
     maps = np.array(maps)
-    rec = dict(branch=[], net=[], crash=[], action=[], best=[], n_alt=[], maps_sha=[], status=[], pos=[])
+    rec = dict(branch=[], net=[], crash=[], action=[], best=[], n_alt=[], maps_sha=[], status=[], pos=[], malf=[])
     obs_h = hashlib.sha256()
     altmaps = [None] * A
     altpaths = [[] for _ in range(A)]
@@ -113,6 +113,7 @@ def run_trace(env, obs_builder, preprocessor, n_steps, hash_obs=True):
         rec["status"].append([int(ag.status) for ag in env.agents])
         rec["pos"].append([(-1 if ag.position is None else ag.position[0] * env.width + ag.position[1])
                            for ag in env.agents])
+        rec["malf"].append([int(info["malfunction"][a]) for a in range(A)])
         if step % 10 == 9 or step == n_steps - 1:
             snapshots[step] = maps.astype(np.int8).copy()
         if done["__all__"]:

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from tests.golden_util import GOLDEN, load_env, load_golden, dense_from_runs, path_rows_of
-from tests.test_oracle_rollout import shim_env, compare_trace
+from tests.test_oracle_rollout import shim_env, compare_trace, malfunction_of
 
 pytestmark = pytest.mark.gpu
 TRACES = sorted(glob.glob(os.path.join(GOLDEN, "rollout", "*.npz")))
@@ -26,7 +26,7 @@ def test_dropin_replays_trace(path):
     name = os.path.basename(path).split("_a")[0]
     A, depth, steps = int(gold["agents"]), int(gold["depth"]), int(gold["steps"])
     ob = RailObsForRailEnv(ShortestPathPredictorForRailEnv(depth))
-    env = shim_env(load_env(name), ob, A)
+    env = shim_env(load_env(name), ob, A, malfunction_of(gold))
     rec, snaps = run_trace(env, ob, ObsPreprocessor(int(gold["max_rails"]), False), steps)
     compare_trace(rec, snaps, gold)
 

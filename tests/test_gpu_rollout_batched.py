@@ -13,18 +13,22 @@ import numpy as np
 import pytest
 
 from tests.golden_util import GOLDEN, load_env, dense_from_runs
+from tests.test_oracle_rollout import malfunction_of
 
 pytestmark = pytest.mark.gpu
 TRACES = sorted(glob.glob(os.path.join(GOLDEN, "rollout", "*.npz")))
 
 
-def _rollout(fx, A, depth, max_rails, E):
+def _rollout(fx, A, depth, max_rails, E, malfunction=None):
     import flatland_marl_amd as fm
     from flatland_marl_amd.rollout import RolloutBatch
     rep = lambda x: np.repeat(np.asarray(x)[None, :A], E, axis=0)
     b = fm.ObservationBatch(np.repeat(fx["grid"][None], E, axis=0), rep(fx["initial_position"]),
                             rep(fx["initial_direction"]), rep(fx["target"]), rep(fx["speed"]), depth, max_rails=max_rails)
-    return RolloutBatch(b, rep(fx["speed"]), rep(fx["initial_direction"])).reset()
+    if malfunction is not None:
+        # every copy draws from the recorded environment's seed so that the copies stay in lockstep
+        malfunction = dict(malfunction, env_seeds=[malfunction["seed"]] * E)
+    return RolloutBatch(b, rep(fx["speed"]), rep(fx["initial_direction"]), malfunction=malfunction).reset()
 
 
 @pytest.mark.parametrize("path", TRACES, ids=[os.path.basename(p)[:-4] for p in TRACES])
@@ -35,7 +39,7 @@ def test_batched_rollout_replays_trace(path):
     name = os.path.basename(path).split("_a")[0]
     A, depth, steps, Rp = int(gold["agents"]), int(gold["depth"]), int(gold["n_steps_run"]), int(gold["max_rails"])
     E = 3
-    ro = _rollout(load_env(name), A, depth, Rp, E)
+    ro = _rollout(load_env(name), A, depth, Rp, E, malfunction_of(gold))
     b = ro.b
     T1 = b.T1
     R = int(b.R[0])
@@ -87,6 +91,9 @@ def test_batched_rollout_replays_trace(path):
             g = got.cpu().numpy()
             assert (g == g[0]).all(), (k, t)
             assert np.array_equal(g[0], gold[k][t]), (k, t, g[0], gold[k][t])
+        if ro.malfunction is not None:
+            g = ro.malfunction.cpu().numpy()
+            assert (g == g[0]).all() and np.array_equal(g[0], gold["malf"][t]), t
         maps = ro.maps_numpy(0, R)
         assert hashlib.sha256(np.ascontiguousarray(maps).tobytes()).hexdigest() == str(gold["maps_sha"][t]), t
         assert np.array_equal(ro.maps_numpy(E - 1, R), maps)

@@ -33,13 +33,17 @@ def main():
     ap.add_argument("--train", action="store_true")
     ap.add_argument("--eps", type=float, default=0.1)
     ap.add_argument("--alt-depth", type=int, default=500)
+    ap.add_argument("--malfunction-rate", type=int, default=2000, help="0 switches the malfunction process off")
+    ap.add_argument("--min-duration", type=int, default=0)
+    ap.add_argument("--max-duration", type=int, default=0)
     args = ap.parse_args()
     names, E, A, depth, desc = bench.WORKLOADS[args.workload]
     E = args.envs or E
     data = make_batch(bench.load_fixtures(names), E, A, seed=0)
     b = fm.ObservationBatch(data["grid"], data["start"], data["direction"], data["target"], data["speed"], depth,
                             max_rails=args.max_rails or None)
-    ro = RolloutBatch(b, data["speed"], data["direction"], max_alt_depth=args.alt_depth).reset()
+    malf = dict(rate=args.malfunction_rate, min_duration=args.min_duration, max_duration=args.max_duration, seed=0)
+    ro = RolloutBatch(b, data["speed"], data["direction"], max_alt_depth=args.alt_depth, malfunction=malf).reset()
     torch.cuda.synchronize()
     out = dict(workload=args.workload, E=E, A=A, Rp=int(b.Rp), T1=b.T1)
 
