@@ -10,9 +10,13 @@ over E environments at once, everything resident on the GPU.
                    of the agents that consulted the network are stored (src/main.py:269-299, default mode) and
                    the learner runs once per `update_every` stored transitions (src/agent.py:55-67).
 
+                   Both replay-feeding modes of the script are there: the default one and switch-to-switch
+                   (src/main.py:280-296), as well as the crash penalty (src/main.py:271-273).
+
 Differences from the sequential script, all inherent to stepping many environments together: the learn
-steps of one rollout step sample a memory that already holds all of that step's transitions; random numbers
-come from one device generator; the switch-to-switch replay mode (src/main.py:280-296) is not implemented.
+steps of one rollout step sample a memory that already holds all of that step's transitions (and the
+transitions of one step enter the memory grouped by kind, not agent by agent); random numbers come from one
+device generator.
 """
 import numpy as np
 import torch
@@ -155,7 +159,7 @@ class DeviceReplay:
 
 class BatchedTrainer:
     def __init__(self, rollout: RolloutBatch, agent, replay_capacity=None, max_steps=200, start_eps=1.0, end_eps=0.005,
-                 eps_decay=0.998, crash_penalty=False, max_learns_per_step=None, seed=0):
+                 eps_decay=0.998, crash_penalty=False, switch2switch=False, max_learns_per_step=None, seed=0):
         self.ro = rollout
         self.agent = agent
         b = rollout.b
@@ -168,6 +172,19 @@ class BatchedTrainer:
         self.max_steps = max_steps
         self.eps, self.end_eps, self.eps_decay = start_eps, end_eps, eps_decay
         self.crash_penalty = crash_penalty
+        self.switch2switch = switch2switch
+        # curr_obs of src/main.py:165,213 (the observation an agent last acted on) and, for the
+        # switch-to-switch mode, buffer_obs / buffer_rew of src/main.py:123,131: one slot per agent
+        n = rollout.E * rollout.A
+        dev = rollout.device
+        self.curr_obs = self.buf_obs = None
+        if crash_penalty or switch2switch:
+            self.curr_obs = torch.zeros((n, 3, b.plane_stride), dtype=torch.uint8, device=dev)
+            self.has_curr = torch.zeros((n,), dtype=torch.bool, device=dev)
+        if switch2switch:
+            self.buf_obs = torch.zeros((n, 3, b.plane_stride), dtype=torch.uint8, device=dev)
+            self.has_buf = torch.zeros((n,), dtype=torch.bool, device=dev)
+            self.buf_rew = torch.zeros((n,), dtype=torch.float64, device=dev)
         self.max_learns_per_step = max_learns_per_step
         self.t_step = 0
         self.n_learn = 0
@@ -188,26 +205,55 @@ class BatchedTrainer:
         ro.step(self.policy)
         last = self.policy.last
         n_new = 0
-        if train and last is not None:
-            for req32, obs, _ in last:
-                req = req32.long()
-                if req.numel() == 0:
-                    continue
-                # the observation after the step: the agent's own plane against everybody's (src/main.py:277)
-                next_obs = ro.consult_observations(req32.contiguous())
-                reward = ro.reward.view(-1)[req]
-                done = ro.done.view(-1)[req]
-                net_out = ro.net.view(-1)[req]             # the decision after the crash checks (src/main.py:180, 225)
-                self.replay.add(obs, net_out, reward, next_obs, done)
-                n_new += req.numel()
-                if self.crash_penalty:                     # src/main.py:271-273, for the agents that consulted this step
-                    cr = ro.crash.view(-1)[req] != 0
-                    k = int(cr.sum().item())
+        if train and (last is not None or self.curr_obs is not None):
+            dev = ro.device
+            groups = [(r, o) for r, o, _ in (last or []) if r.numel()]
+            if self.curr_obs is not None:
+                for req32, obs in groups:
+                    self.curr_obs[req32.long()] = obs
+                    self.has_curr[req32.long()] = True
+            if self.crash_penalty:                         # src/main.py:271-273: every agent whose check failed
+                idx = torch.nonzero((ro.crash.view(-1) != 0) & self.has_curr).view(-1)
+                k = idx.numel()
+                if k:
+                    o = self.curr_obs[idx]
+                    self.replay.add(o, torch.ones(k, dtype=torch.int64, device=dev),
+                                    torch.full((k,), -100.0, device=dev), o, torch.ones(k, device=dev))
+                    n_new += k
+            if not self.switch2switch:                     # src/main.py:275-278
+                for req32, obs in groups:
+                    req = req32.long()
+                    # the observation after the step: the agent's own plane against everybody's
+                    next_obs = ro.consult_observations(req32.contiguous())
+                    # the decision stored is the one after the crash checks (src/main.py:180, 225)
+                    self.replay.add(obs, ro.net.view(-1)[req], ro.reward.view(-1)[req], next_obs, ro.done.view(-1)[req])
+                    n_new += req.numel()
+            else:                                          # src/main.py:280-296
+                reward_all = ro.reward.view(-1)
+                if groups:
+                    req = torch.cat([r for r, _ in groups]).long()
+                    net_out = ro.net.view(-1)[req]
+                    # an observation kept since the previous decision meets the current one
+                    idx = req[self.has_buf[req]]
+                    k = idx.numel()
                     if k:
-                        o = obs[cr]
-                        self.replay.add(o, torch.ones(k, dtype=torch.int64, device=ro.device),
-                                        torch.full((k,), -100.0, device=ro.device), o, torch.ones(k, device=ro.device))
+                        self.replay.add(self.buf_obs[idx], torch.ones(k, dtype=torch.int64, device=dev),
+                                        self.buf_rew[idx], self.curr_obs[idx], ro.done.view(-1)[idx])
+                        self.has_buf[idx] = False
+                        self.buf_rew[idx] = 0
                         n_new += k
+                    stop = req[net_out == 0]               # stored with action 1, as the script does (src/main.py:289)
+                    k = stop.numel()
+                    if k:
+                        o = self.curr_obs[stop]
+                        self.replay.add(o, torch.ones(k, dtype=torch.int64, device=dev), reward_all[stop], o,
+                                        torch.zeros(k, device=dev))
+                        n_new += k
+                    go = req[net_out == 1]                 # kept until the agent's next decision
+                    if go.numel():
+                        self.buf_obs[go] = self.curr_obs[go]
+                        self.has_buf[go] = True
+                self.buf_rew += torch.where(self.has_buf, reward_all, torch.zeros_like(reward_all))
             self.n_transitions += n_new
             # src/agent.py:57-67: one learn step per update_every stored transitions, once the memory is large enough
             due = (self.t_step + n_new) // self.agent.args.update_every
@@ -229,6 +275,10 @@ class BatchedTrainer:
         """env.reset() + up to max_steps-1 steps (src/main.py:135-311) -> summary of the episode."""
         ro = self.ro
         ro.reset()
+        if self.curr_obs is not None:
+            self.has_curr.zero_()                          # curr_obs starts empty every episode (src/main.py:133)
+        if self.buf_obs is not None:
+            self.buf_rew.zero_()                           # src/main.py:131; buffer_obs itself outlives the episode (:123)
         total_reward = torch.zeros((ro.E,), dtype=torch.float64, device=ro.device)
         steps = 0
         for _ in range(self.max_steps - 1):

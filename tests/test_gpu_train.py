@@ -77,3 +77,77 @@ def test_training_episode_runs_and_learns():
     assert bool(((r <= 0) | (r == -100)).all())
     out2 = tr.run_episode(train=True)                         # a second episode resets cleanly
     assert out2["steps"] >= 1 and out2["eps"] < 0.5
+
+
+def _hash(t):
+    import hashlib
+    return hashlib.sha1(t.contiguous().cpu().numpy().tobytes()).hexdigest()[:16]
+
+
+@pytest.mark.parametrize("s2s,penalty", [(False, True), (True, False), (True, True)])
+def test_replay_feeding_follows_the_script(s2s, penalty):
+    """What enters the replay memory, step by step, against the per-agent rules of src/main.py:269-299 written
+    out as the script has them (sequential, one agent at a time) and fed with the same per-step facts."""
+    import torch
+    from collections import Counter
+    ro, agent, tr = _setup(E=3, A=12, depth=60, name="Test_2_Level_0", start_eps=0.4, crash_penalty=penalty,
+                           switch2switch=s2s, replay_capacity=4000)
+    agent.args.batch_size = 10 ** 9                           # never learn: only the feeding is under test
+    stored = []
+    add = tr.replay.add
+
+    def recording_add(state, action, reward, next_state, done):
+        for k in range(state.shape[0]):
+            stored.append((_hash(state[k]), int(action[k]), float(reward[k].to(torch.float32)), _hash(next_state[k]),
+                           bool(done[k])))
+        add(state, action, reward, next_state, done)
+    tr.replay.add = recording_add
+
+    n = ro.E * ro.A
+    curr_obs = [None] * n
+    buffer_obs = [None] * n                                   # None plays the role of the script's empty list
+    buffer_rew = [0.0] * n
+    buffer_done = [False] * n
+    total = 0
+    for t in range(70):
+        del stored[:]
+        tr.step(train=True)
+        torch.cuda.synchronize()
+        update = [False] * n
+        for req, obs, _ in (tr.policy.last or []):
+            for k, g in enumerate(req.cpu().numpy()):
+                update[g] = True
+                curr_obs[g] = obs[k]
+        net = ro.net.view(-1).cpu().numpy()
+        crash = ro.crash.view(-1).cpu().numpy()
+        reward = ro.reward.view(-1).cpu().numpy()
+        done = ro.done.view(-1).cpu().numpy().astype(bool)
+        want = []
+        for g in range(n):
+            if penalty and crash[g]:
+                h = _hash(curr_obs[g])
+                want.append((h, 1, -100.0, h, True))
+            if not s2s:
+                if update[g] and not buffer_done[g]:
+                    nxt = ro.consult_observations(torch.tensor([g], dtype=torch.int32, device=ro.device))[0]
+                    want.append((_hash(curr_obs[g]), int(net[g]), float(np.float32(reward[g])), _hash(nxt), bool(done[g])))
+            else:
+                if update[g] and not buffer_done[g]:
+                    if buffer_obs[g] is not None:
+                        want.append((_hash(buffer_obs[g]), 1, float(np.float32(buffer_rew[g])), _hash(curr_obs[g]),
+                                     bool(done[g])))
+                        buffer_obs[g] = None
+                        buffer_rew[g] = 0.0
+                    if net[g] == 0:
+                        h = _hash(curr_obs[g])
+                        want.append((h, 1, float(np.float32(reward[g])), h, False))
+                    elif net[g] == 1:
+                        buffer_obs[g] = curr_obs[g].clone()
+                if buffer_obs[g] is not None:
+                    buffer_rew[g] += reward[g]
+            buffer_done[g] = done[g]
+        assert Counter(stored) == Counter(want), t
+        total += len(want)
+    assert total > 100
+    if s2s:
+        assert any(x is not None for x in buffer_obs)
