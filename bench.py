@@ -32,11 +32,27 @@ WORKLOADS = {
              "256 envs x 200 agents, 150x150 grid (Test_9-class maps), depth 300"),
     "cfg2": (["Test_2_Level_0", "Test_2_Level_1"], 1024, 10, 150,
              "1024 envs x 10 agents, 35x35 grid (Test_2-class maps stand in for 25x25), max_rails 70+, depth 150"),
+    # the same shape on grids from the package's own generator (flatland's generator is not available)
+    "cfg2g": (dict(H=25, W=25, n_maps=8, spacing=4, max_rails=70), 1024, 10, 150,
+              "1024 envs x 10 agents, generated 25x25 grids (8 grids x 8 symmetries), max_rails 70, depth 150"),
 }
 
 
 def load_fixtures(names):
     return [dict(np.load(os.path.join(ROOT, "tests", "golden", "envs", n + ".npz"))) for n in names]
+
+
+def workload_batch(name, E=0, seed=0):
+    """-> (data, E, A, depth, description) of a named workload; E = 0 takes the workload's own size."""
+    from flatland_marl_amd.synthetic import make_batch
+    from flatland_marl_amd.railgen import make_generated_batch
+    src, E0, A, depth, desc = WORKLOADS[name]
+    E = E or E0
+    if isinstance(src, dict):
+        data = make_generated_batch(E, A, seed=seed, depth=depth, **src)
+    else:
+        data = make_batch(load_fixtures(src), E, A, seed=seed)
+    return data, E, A, depth, desc
 
 
 def cpu_baseline(data, depth, Rp, budget_s=12.0, max_envs=64):
@@ -64,7 +80,7 @@ def cpu_baseline(data, depth, Rp, budget_s=12.0, max_envs=64):
                        "C restatement of the reference algorithm (oracle/flmarl_oracle.c)" % (n_env, n_obs, dt))
 
 
-def rollout_sample(device, steps=40):
+def rollout_sample(device, steps=40, workload="cfg2"):
     """Environment steps per second of the batched rollout (src/main.py:142-299 for every environment at once)
     on the 1024 x 10 workload with max_rails = 100 (the reference's setting, src/main.py:91): the network
     consulted by every departing agent and every agent in front of a switch, first without, then with
@@ -73,10 +89,8 @@ def rollout_sample(device, steps=40):
     import flatland_marl_amd as fm
     from flatland_marl_amd.agent import DQNAgent
     from flatland_marl_amd.rollout import RolloutBatch
-    from flatland_marl_amd.synthetic import make_batch
     from flatland_marl_amd.train import BatchedTrainer
-    names, E, A, depth, desc = WORKLOADS["cfg2"]
-    data = make_batch(load_fixtures(names), E, A, seed=0)
+    data, E, A, depth, desc = workload_batch(workload)
     b = fm.ObservationBatch(data["grid"], data["start"], data["direction"], data["target"], data["speed"], depth,
                             max_rails=100, device=device)
     # episodes of <= 200 steps (src/main.py:93); malfunction process with the script's defaults (src/main.py:373-375)
@@ -86,7 +100,7 @@ def rollout_sample(device, steps=40):
                               gamma=0.99, tau=1e-3)
     agent = DQNAgent(a, action_space=2, bitmap_height=3 * b.Rp)
     tr = BatchedTrainer(ro, agent, start_eps=0.1, max_learns_per_step=4)
-    out = {"unit": "env-steps/s", "config": {"workload": "cfg2: " + desc, "envs": E, "agents": A, "rails_padded": int(b.Rp),
+    out = {"unit": "env-steps/s", "config": {"workload": workload + ": " + desc, "envs": E, "agents": A, "rails_padded": int(b.Rp),
                                              "depth": depth, "steps_timed": steps, "eps": 0.1,
                                              "speeds": "1, 1/2, 1/3, 1/4", "malfunction": malf}}
     for key, train in (("act_only", False), ("act_and_learn", True)):
@@ -129,14 +143,10 @@ def main():
 
     import flatland_marl_amd as fm
     from flatland_marl_amd import parallel
-    from flatland_marl_amd.synthetic import make_batch
     from flatland_marl_amd.batch import plane_stride_for
     parallel.init_distributed("nccl", device)
 
-    names, E, A, depth, desc = WORKLOADS[args.workload]
-    if args.envs:
-        E = args.envs
-    data = make_batch(load_fixtures(names), E, A, seed=1000003 * rank)
+    data, E, A, depth, desc = workload_batch(args.workload, args.envs, seed=1000003 * rank)
     # The batch is processed as `chunks` sub-batches spread over `streams` HIP streams, so that the
     # latency-bound kernels of one sub-batch (graph, distances, paths) overlap the bandwidth-bound
     # observation kernel of another.

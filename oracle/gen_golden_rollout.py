@@ -32,6 +32,9 @@ CASES = [
     ("Test_2_Level_1", 80, 150, 100),
     ("Test_3_Level_0", 30, 150, 150),
     ("Test_5_Level_0", 25, 100, 199),
+    # grids from the package's own generator (tests/golden/make_generated_fixtures.py)
+    ("Gen_25x25_0", 10, 150, 150),
+    ("Gen_64x64_3", 40, 150, 199),
 ]
 # the same driver with the stand-in's malfunction process switched on: (fixture, agents, depth, steps,
 # rate, min_duration, max_duration, seed).  The reference's loop never looks at malfunctions, so its
@@ -49,7 +52,10 @@ def main():
     only_malfunction = "--malfunction-only" in sys.argv
     cases = [] if only_malfunction else [c + (None,) for c in CASES]
     cases += [c[:4] + (dict(rate=c[4], min_duration=c[5], max_duration=c[6], seed=c[7]),) for c in MALFUNCTION_CASES]
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]
     for name, A, depth, steps, malf in cases:
+        if only and name not in only:
+            continue
         t0 = time.time()
         fx = np.load(os.path.join(ROOT, "tests", "golden", "envs", name + ".npz"))
         ob = RailObsForRailEnv(ShortestPathPredictorForRailEnv(depth))

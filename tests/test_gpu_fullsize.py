@@ -15,10 +15,8 @@ def _workload(name):
     import sys
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
-    from bench import WORKLOADS, load_fixtures
-    from flatland_marl_amd.synthetic import make_batch
-    names, E, A, depth, _ = WORKLOADS[name]
-    return make_batch(load_fixtures(names), E, A, seed=0), E, A, depth
+    from bench import workload_batch
+    return workload_batch(name)[:4]
 
 
 def _checksum(t):
@@ -28,7 +26,7 @@ def _checksum(t):
     return int(flat[:n8].view(torch.int64).sum().item()) + int(flat[n8:].sum(dtype=torch.int64).item())
 
 
-@pytest.mark.parametrize("name,n_sample", [("cfg3", 12), ("cfg5", 2), ("cfg2", 24)])
+@pytest.mark.parametrize("name,n_sample", [("cfg3", 12), ("cfg5", 2), ("cfg2", 24), ("cfg2g", 24)])
 def test_full_size_workload(name, n_sample):
     import torch
     import flatland_marl_amd as fm

@@ -14,7 +14,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 import flatland_marl_amd as fm  # noqa: E402
-from flatland_marl_amd.synthetic import make_batch  # noqa: E402
 
 
 def timed(fn, reps=5, warm=1):
@@ -36,9 +35,7 @@ def main():
     ap.add_argument("--envs", type=int, default=0)
     ap.add_argument("--stages", default="graph,bfs,paths,bitmaps,obs,fused")
     args = ap.parse_args()
-    names, E, A, depth, desc = bench.WORKLOADS[args.workload]
-    E = args.envs or E
-    data = make_batch(bench.load_fixtures(names), E, A, seed=0)
+    data, E, A, depth, desc = bench.workload_batch(args.workload, args.envs)
     b = fm.ObservationBatch(data["grid"], data["start"], data["direction"], data["target"], data["speed"], depth)
     b.reset()
     b.observations()

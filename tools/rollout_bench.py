@@ -20,7 +20,6 @@ import bench  # noqa: E402
 import flatland_marl_amd as fm  # noqa: E402
 from flatland_marl_amd.agent import DQNAgent  # noqa: E402
 from flatland_marl_amd.rollout import RolloutBatch, hash_policy  # noqa: E402
-from flatland_marl_amd.synthetic import make_batch  # noqa: E402
 from flatland_marl_amd.train import BatchedTrainer  # noqa: E402
 
 
@@ -37,9 +36,7 @@ def main():
     ap.add_argument("--min-duration", type=int, default=0)
     ap.add_argument("--max-duration", type=int, default=0)
     args = ap.parse_args()
-    names, E, A, depth, desc = bench.WORKLOADS[args.workload]
-    E = args.envs or E
-    data = make_batch(bench.load_fixtures(names), E, A, seed=0)
+    data, E, A, depth, desc = bench.workload_batch(args.workload, args.envs)
     b = fm.ObservationBatch(data["grid"], data["start"], data["direction"], data["target"], data["speed"], depth,
                             max_rails=args.max_rails or None)
     malf = dict(rate=args.malfunction_rate, min_duration=args.min_duration, max_duration=args.max_duration, seed=0)
