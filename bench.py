@@ -80,27 +80,33 @@ def cpu_baseline(data, depth, Rp, budget_s=12.0, max_envs=64):
                        "C restatement of the reference algorithm (oracle/flmarl_oracle.c)" % (n_env, n_obs, dt))
 
 
-def rollout_sample(device, steps=40, workload="cfg2"):
+def rollout_sample(device, steps=40, workload="cfg2g", max_rails=70, rank=0, world=1):
     """Environment steps per second of the batched rollout (src/main.py:142-299 for every environment at once)
-    on the 1024 x 10 workload with max_rails = 100 (the reference's setting, src/main.py:91): the network
+    on the 1024 x 10 workload (generated 25x25 grids, max_rails = 70; the script itself pads to 100 rails,
+    src/main.py:91, which --rollout-max-rails 100 reproduces): the network
     consulted by every departing agent and every agent in front of a switch, first without, then with
-    learning (one learn step per 10 stored transitions, at most 4 per rollout step)."""
+    learning (one learn step per 10 stored transitions, at most 4 per rollout step).  With several ranks every
+    rank steps environments of its own and the learn steps all-reduce the gradient; value = all ranks'
+    environment steps / the slowest rank's time."""
     import types
     import flatland_marl_amd as fm
     from flatland_marl_amd.agent import DQNAgent
     from flatland_marl_amd.rollout import RolloutBatch
     from flatland_marl_amd.train import BatchedTrainer
-    data, E, A, depth, desc = workload_batch(workload)
+    from flatland_marl_amd import parallel
+    data, E, A, depth, desc = workload_batch(workload, seed=1000003 * rank)
     b = fm.ObservationBatch(data["grid"], data["start"], data["direction"], data["target"], data["speed"], depth,
-                            max_rails=100, device=device)
+                            max_rails=max_rails, device=device)
     # episodes of <= 200 steps (src/main.py:93); malfunction process with the script's defaults (src/main.py:373-375)
     malf = dict(rate=2000, min_duration=0, max_duration=0, seed=0)
     ro = RolloutBatch(b, data["speed"], data["direction"], max_alt_depth=max(200, depth + 1) + 2, malfunction=malf).reset()
     a = types.SimpleNamespace(prediction_depth=depth, lr=5e-5, buffer_size=20000, batch_size=512, update_every=10,
                               gamma=0.99, tau=1e-3)
+    torch.manual_seed(0)                                     # identical replicas on every rank
     agent = DQNAgent(a, action_space=2, bitmap_height=3 * b.Rp)
-    tr = BatchedTrainer(ro, agent, start_eps=0.1, max_learns_per_step=4)
-    out = {"unit": "env-steps/s", "config": {"workload": workload + ": " + desc, "envs": E, "agents": A, "rails_padded": int(b.Rp),
+    tr = BatchedTrainer(ro, agent, start_eps=0.1, max_learns_per_step=4, seed=rank)
+    out = {"unit": "env-steps/s", "config": {"workload": workload + ": " + desc, "envs_per_gpu": E, "n_gpus": world,
+                                             "agents": A, "rails_padded": int(b.Rp),
                                              "depth": depth, "steps_timed": steps, "eps": 0.1,
                                              "speeds": "1, 1/2, 1/3, 1/4", "malfunction": malf}}
     for key, train in (("act_only", False), ("act_and_learn", True)):
@@ -109,14 +115,39 @@ def rollout_sample(device, steps=40, workload="cfg2"):
             tr.step(train=train)
         n0, l0 = tr.n_transitions, tr.n_learn
         torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             tr.step(train=train)
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        out[key] = {"value": E / dt, "ms_per_step": dt * 1e3, "transitions_per_step": (tr.n_transitions - n0) / steps,
+        dt = parallel.max_over_ranks(time.perf_counter() - t0, device) / steps
+        out[key] = {"value": E * world / dt, "ms_per_step": dt * 1e3,
+                    "transitions_per_step": (tr.n_transitions - n0) / steps,
                     "learn_steps_per_step": (tr.n_learn - l0) / steps}
     return out
+
+
+def guarded_rollout_sample(out, rank, timeout_s, **kw):
+    """Runs rollout_sample under a watchdog: the main JSON line must come out even if the sample stalls (a
+    collective that one rank never enters).  On expiry rank 0 prints the line without the sample and every
+    rank leaves."""
+    import threading
+
+    def expire():
+        if rank == 0:
+            out["env_steps"] = {"error": "no result within %d s" % timeout_s}
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+    timer = threading.Timer(timeout_s, expire)
+    timer.daemon = True
+    timer.start()
+    try:
+        res = rollout_sample(rank=rank, **kw)
+    except Exception as ex:            # noqa: BLE001 - reported in the line, the observation figures stand
+        res = {"error": repr(ex)}
+    timer.cancel()
+    return res
 
 
 def main():
@@ -133,6 +164,8 @@ def main():
                          "2: pipelined, the other stages of the next sub-batch run on a side stream meanwhile")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rollout", action="store_true", help="skip the env-steps/s sample of the batched rollout")
+    ap.add_argument("--rollout-workload", default="cfg2g", choices=["cfg2", "cfg2g"])
+    ap.add_argument("--rollout-max-rails", type=int, default=70)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -256,6 +289,7 @@ def main():
     obs_ms = float(np.mean([a.elapsed_time(b) for per_step in events for a, b in per_step]))
     E_launch = batches[0].E
 
+    out = {}
     if rank == 0:
         total_obs = E * A * world * args.steps
         alg_bytes = 4.0 * Rp * T1 * E_launch * A   # per launch of the observation kernel
@@ -290,9 +324,12 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data, depth, int(Rp))
-        if world == 1 and not args.no_rollout:
-            out["env_steps"] = rollout_sample(device)
-        print(json.dumps(out))
+    if not args.no_rollout:
+        res = guarded_rollout_sample(out, rank, 240, device=device, workload=args.rollout_workload,
+                                     max_rails=args.rollout_max_rails, world=world)
+        out["env_steps"] = res
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 
