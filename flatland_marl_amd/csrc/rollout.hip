@@ -5,22 +5,27 @@
 namespace flm {
 
 // ---- alternative paths ------------------------------------------------------------------------------
-// One thread per request.  The branching prefix (the cell the agent stands on, then every switch cell
-// crossed before the first plain cell) is enumerated depth-first in the order left, forward, right;
-// every leaf is completed by a greedy descent of at most max_depth moves.
+// A group of G lanes per request (G = power of two >= cap_alt, 64 / G requests per wave).  The group's
+// first lane enumerates the branching prefix (the cell the agent stands on, then every switch cell crossed
+// before the first plain cell) depth-first in the order left, forward, right and writes one prefix per
+// leaf; then every lane completes one leaf by a greedy descent of at most max_depth moves, so the walks of
+// a request run side by side; last, leaves whose descent found no way are squeezed out in order.
+// More than cap_alt leaves is FLM_AGENT_OVERFLOW.
 #define FLM_ALT_STACK 32
 
-__global__ void altpaths_kernel(const uint16_t* __restrict__ grid_all, const int32_t* __restrict__ cell_idx_all,
-                                const uint16_t* __restrict__ dist_all, const uint16_t* __restrict__ succ_all,
-                                const int32_t* __restrict__ tslot, const int32_t* __restrict__ node_id_all, const int32_t* __restrict__ req_agent, int n_req,
-                                const int32_t* __restrict__ pos_cell, const int32_t* __restrict__ direction,
-                                const int32_t* __restrict__ target_cell, int A, int H, int W, int capCells,
-                                int max_depth, int cap_alt, int Lcap, int32_t* __restrict__ alt_count,
-                                int32_t* __restrict__ alt_len, int32_t* __restrict__ alt_cell,
-                                uint32_t* __restrict__ alt_meta, int32_t* __restrict__ err_out) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n_req) return;
-  const int ga = req_agent[g];
+__global__ __launch_bounds__(64) void altpaths_kernel(
+    const uint16_t* __restrict__ grid_all, const int32_t* __restrict__ cell_idx_all,
+    const uint16_t* __restrict__ dist_all, const uint16_t* __restrict__ succ_all, const int32_t* __restrict__ tslot,
+    const int32_t* __restrict__ node_id_all, const int32_t* __restrict__ req_agent, int n_req,
+    const int32_t* __restrict__ pos_cell, const int32_t* __restrict__ direction,
+    const int32_t* __restrict__ target_cell, int A, int H, int W, int capCells, int max_depth, int cap_alt, int Lcap,
+    int G, int32_t* __restrict__ alt_count, int32_t* __restrict__ alt_len, int32_t* __restrict__ alt_cell,
+    uint32_t* __restrict__ alt_meta, int32_t* __restrict__ err_out) {
+  __shared__ int s_cell[64], s_h[64], s_base[64], s_res[64], s_n[64], s_err[64];
+  const int lane = threadIdx.x, grp = lane / G, j = lane - grp * G;
+  const int g = blockIdx.x * (64 / G) + grp;
+  const bool live = g < n_req;
+  const int ga = live ? req_agent[g] : 0;
   const int e = ga / A;
   const int HW = H * W;
   const uint16_t* grid = grid_all + (size_t)e * HW;
@@ -29,86 +34,118 @@ __global__ void altpaths_kernel(const uint16_t* __restrict__ grid_all, const int
   const uint16_t* dist = dist_all + ((size_t)e * A + tslot[ga]) * capCells * 4;
   const uint16_t* succ = succ_all ? succ_all + (size_t)e * capCells * 4 : nullptr;
   const int tcell = target_cell[ga];
-  const int pos = pos_cell[ga], h0 = direction[ga] & 3;
   int32_t* out_len = alt_len + (size_t)g * cap_alt;
-  int n_alt = 0, err = 0;
+  int32_t* slot_cell = alt_cell + (size_t)g * cap_alt * Lcap;
+  uint32_t* slot_meta = alt_meta + (size_t)g * cap_alt * Lcap;
+  int n_leaf = 0, err = 0;
 
-  // prefix elements (cell, meta) and DFS frames over switch cells
-  int pre_cell[FLM_ALT_STACK + 2];
-  unsigned pre_meta[FLM_ALT_STACK + 2];
-  int f_cell[FLM_ALT_STACK], f_h[FLM_ALT_STACK], f_i[FLM_ALT_STACK], f_k[FLM_ALT_STACK];
-  int f_act[FLM_ALT_STACK][3], f_nd[FLM_ALT_STACK][3];
-
-  if (pos == tcell || pos < 0 || pos >= HW) {
-    err = FLM_AGENT_ASSERT_ERROR;
-  } else {
-    int act0[3], nd0[3];
-    const int k0 = valid_moves(grid[pos], h0, act0, nd0);
-    const int pr = pos / W, pc = pos - pr * W;
-    for (int i0 = 0; i0 < k0 && !err; i0++) {
-      // the first element is always recorded as "forward"
-      pre_cell[0] = pos;
-      pre_meta[0] = (unsigned)h0 | (2u << 8) | ((unsigned)nd0[i0] << 16);
-      int np = 1, depth = 0;
-      {
-        int nr = pr + dr(nd0[i0]), nc = pc + dc(nd0[i0]);
-        if (nr < 0 || nr >= H || nc < 0 || nc >= W) { err = FLM_AGENT_ASSERT_ERROR; break; }
-        f_cell[0] = nr * W + nc;
-        f_h[0] = nd0[i0];
-        f_i[0] = 0;
-        f_k[0] = valid_moves(grid[f_cell[0]], f_h[0], f_act[0], f_nd[0]);
-        depth = 1;
-      }
-      while (depth > 0 && !err) {
-        const int d = depth - 1;
-        const int cell = f_cell[d], h = f_h[d];
-        const int r = cell / W, c = cell - r * W;
-        if (node_id[cell] >= 0) {
-          if (f_i[d] > 0) np--;  // back from the previous branch
-          if (f_i[d] < f_k[d]) {
-            const int i = f_i[d]++;
-            pre_cell[np] = cell;
-            pre_meta[np] = (unsigned)h | ((unsigned)f_act[d][i] << 8) | ((unsigned)f_nd[d][i] << 16);
-            np++;
-            int nr = r + dr(f_nd[d][i]), nc = c + dc(f_nd[d][i]);
-            if (depth >= FLM_ALT_STACK || nr < 0 || nr >= H || nc < 0 || nc >= W) { err = FLM_AGENT_OVERFLOW; break; }
-            f_cell[depth] = nr * W + nc;
-            f_h[depth] = f_nd[d][i];
-            f_i[depth] = 0;
-            f_k[depth] = valid_moves(grid[f_cell[depth]], f_h[depth], f_act[depth], f_nd[depth]);
-            depth++;
+  if (live && j == 0) {
+    const int pos = pos_cell[ga], h0 = direction[ga] & 3;
+    // prefix elements (cell, meta) and DFS frames over switch cells
+    int pre_cell[FLM_ALT_STACK + 2];
+    unsigned pre_meta[FLM_ALT_STACK + 2];
+    int f_cell[FLM_ALT_STACK], f_h[FLM_ALT_STACK], f_i[FLM_ALT_STACK], f_k[FLM_ALT_STACK];
+    int f_act[FLM_ALT_STACK][3], f_nd[FLM_ALT_STACK][3];
+    if (pos == tcell || pos < 0 || pos >= HW) {
+      err = FLM_AGENT_ASSERT_ERROR;
+    } else {
+      int act0[3], nd0[3];
+      const int k0 = valid_moves(grid[pos], h0, act0, nd0);
+      const int pr = pos / W, pc = pos - pr * W;
+      for (int i0 = 0; i0 < k0 && !err; i0++) {
+        // the first element is always recorded as "forward"
+        pre_cell[0] = pos;
+        pre_meta[0] = (unsigned)h0 | (2u << 8) | ((unsigned)nd0[i0] << 16);
+        int np = 1, depth = 0;
+        {
+          int nr = pr + dr(nd0[i0]), nc = pc + dc(nd0[i0]);
+          if (nr < 0 || nr >= H || nc < 0 || nc >= W) { err = FLM_AGENT_ASSERT_ERROR; break; }
+          f_cell[0] = nr * W + nc;
+          f_h[0] = nd0[i0];
+          f_i[0] = 0;
+          f_k[0] = valid_moves(grid[f_cell[0]], f_h[0], f_act[0], f_nd[0]);
+          depth = 1;
+        }
+        while (depth > 0 && !err) {
+          const int d = depth - 1;
+          const int cell = f_cell[d], h = f_h[d];
+          const int r = cell / W, c = cell - r * W;
+          if (node_id[cell] >= 0) {
+            if (f_i[d] > 0) np--;  // back from the previous branch
+            if (f_i[d] < f_k[d]) {
+              const int i = f_i[d]++;
+              pre_cell[np] = cell;
+              pre_meta[np] = (unsigned)h | ((unsigned)f_act[d][i] << 8) | ((unsigned)f_nd[d][i] << 16);
+              np++;
+              int nr = r + dr(f_nd[d][i]), nc = c + dc(f_nd[d][i]);
+              if (depth >= FLM_ALT_STACK || nr < 0 || nr >= H || nc < 0 || nc >= W) { err = FLM_AGENT_OVERFLOW; break; }
+              f_cell[depth] = nr * W + nc;
+              f_h[depth] = f_nd[d][i];
+              f_i[depth] = 0;
+              f_k[depth] = valid_moves(grid[f_cell[depth]], f_h[depth], f_act[depth], f_nd[depth]);
+              depth++;
+            } else {
+              depth--;
+            }
           } else {
+            if (f_k[d] != 1) { err = FLM_AGENT_ASSERT_ERROR; break; }
+            if (n_leaf >= cap_alt || np + 1 > Lcap) { err = FLM_AGENT_OVERFLOW; break; }
+            int32_t* oc = slot_cell + (size_t)n_leaf * Lcap;
+            uint32_t* om = slot_meta + (size_t)n_leaf * Lcap;
+            for (int q = 0; q < np; q++) { oc[q] = pre_cell[q]; om[q] = pre_meta[q]; }
+            oc[np] = cell;
+            om[np] = (unsigned)h | ((unsigned)f_act[d][0] << 8) | ((unsigned)f_nd[d][0] << 16);
+            const int nr = r + dr(f_nd[d][0]), nc = c + dc(f_nd[d][0]);
+            // where the descent starts: -1 = the leaf is the target itself, -2 = the move leaves the grid
+            s_cell[grp * G + n_leaf] = cell == tcell ? -1 : (nr >= 0 && nr < H && nc >= 0 && nc < W) ? nr * W + nc : -2;
+            s_h[grp * G + n_leaf] = f_nd[d][0];
+            s_base[grp * G + n_leaf] = np + 1;
+            n_leaf++;
             depth--;
           }
-        } else {
-          if (f_k[d] != 1) { err = FLM_AGENT_ASSERT_ERROR; break; }
-          if (n_alt >= cap_alt || np + 1 > Lcap) { err = FLM_AGENT_OVERFLOW; break; }
-          int32_t* oc = alt_cell + ((size_t)g * cap_alt + n_alt) * Lcap;
-          uint32_t* om = alt_meta + ((size_t)g * cap_alt + n_alt) * Lcap;
-          for (int q = 0; q < np; q++) { oc[q] = pre_cell[q]; om[q] = pre_meta[q]; }
-          oc[np] = cell;
-          om[np] = (unsigned)h | ((unsigned)f_act[d][0] << 8) | ((unsigned)f_nd[d][0] << 16);
-          const int base = np + 1;
-          if (cell == tcell) {
-            out_len[n_alt++] = base;
-          } else {
-            int nr = r + dr(f_nd[d][0]), nc = c + dc(f_nd[d][0]);
-            int n = -1;
-            if (nr >= 0 && nr < H && nc >= 0 && nc < W)
-              n = greedy_path(grid, cell_idx, dist, succ, H, W, nr * W + nc, f_nd[d][0], tcell, max_depth, oc + base, om + base,
-                              Lcap - base);
-            if (n >= 0) {
-              if (base + n > Lcap) { err = FLM_AGENT_OVERFLOW; break; }
-              out_len[n_alt++] = base + n;
-            }
-          }
-          depth--;
         }
       }
     }
+    s_n[grp] = n_leaf;
+    s_err[grp] = err;
   }
-  alt_count[g] = err ? 0 : n_alt;
-  err_out[g] = err;
+  __syncthreads();
+  if (live) {
+    n_leaf = s_n[grp];
+    err = s_err[grp];
+    if (!err && j < n_leaf) {
+      const int start = s_cell[lane], base = s_base[lane];
+      int res = -1;                       // elements of the finished alternative; -1 = no way, -2 = does not fit
+      if (start == -1) {
+        res = base;
+      } else if (start >= 0) {
+        const int n = greedy_path(grid, cell_idx, dist, succ, H, W, start, s_h[lane], tcell, max_depth,
+                                  slot_cell + (size_t)j * Lcap + base, slot_meta + (size_t)j * Lcap + base, Lcap - base);
+        if (n >= 0) res = base + n > Lcap ? -2 : base + n;
+      }
+      s_res[lane] = res;
+    }
+  }
+  __syncthreads();
+  int n_alt = 0;
+  if (live && !err) {
+    for (int q = 0; q < n_leaf; q++) {
+      const int res = s_res[grp * G + q];
+      if (res == -2) { err = FLM_AGENT_OVERFLOW; break; }
+      if (res < 0) continue;
+      if (n_alt != q)                     // an earlier leaf fell out: move this one down (each lane its own elements)
+        for (int i = j; i < res; i += G) {
+          slot_cell[(size_t)n_alt * Lcap + i] = slot_cell[(size_t)q * Lcap + i];
+          slot_meta[(size_t)n_alt * Lcap + i] = slot_meta[(size_t)q * Lcap + i];
+        }
+      if (j == 0) out_len[n_alt] = res;
+      n_alt++;
+    }
+  }
+  if (live && j == 0) {
+    alt_count[g] = err ? 0 : n_alt;
+    err_out[g] = err;
+  }
 }
 
 // ---- occupancy-plane bookkeeping ---------------------------------------------------------------------
@@ -308,11 +345,14 @@ extern "C" int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const
       !alt_count || !alt_len || !alt_cell || !alt_meta || !err)
     return FLM_E_ARG;
   if (E <= 0 || A <= 0 || H <= 0 || W <= 0 || n_req <= 0 || capCells <= 0 || max_depth < 0 || cap_alt <= 0 ||
-      Lcap < max_depth + 4)
+      cap_alt > 64 || Lcap < max_depth + 4)
     return FLM_E_ARG;
-  hipLaunchKernelGGL(flm::altpaths_kernel, dim3((n_req + 63) / 64), dim3(64), 0, (hipStream_t)stream, grid, cell_idx, dist,
-                     succ, tslot, node_id, req_agent, n_req, pos_cell, direction, target_cell, A, H, W, capCells, max_depth,
-                     cap_alt, Lcap, alt_count, alt_len, alt_cell, alt_meta, err);
+  int G = 1;                              // lanes per request
+  while (G < cap_alt) G *= 2;
+  const int per_block = 64 / G;
+  hipLaunchKernelGGL(flm::altpaths_kernel, dim3((n_req + per_block - 1) / per_block), dim3(64), 0, (hipStream_t)stream,
+                     grid, cell_idx, dist, succ, tslot, node_id, req_agent, n_req, pos_cell, direction, target_cell, A, H, W,
+                     capCells, max_depth, cap_alt, Lcap, G, alt_count, alt_len, alt_cell, alt_meta, err);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }

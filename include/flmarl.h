@@ -197,8 +197,9 @@ int flm_reorder_rails(const uint8_t* obs_in, uint8_t* obs_out, int n, int Rp, in
  *   req_agent [n_req] int32: e*A + a of each request; pos_cell/direction/target_cell [E,A] as above
  *   alt_count [n_req] out; alt_len [n_req,cap_alt] out; alt_cell/alt_meta [n_req,cap_alt,Lcap] out in the
  *   path encoding of flm_shortest_paths; err [n_req] out (FLM_AGENT_ASSERT_ERROR where the reference's
- *   assertions at :108/:125 fail, FLM_AGENT_OVERFLOW when cap_alt, Lcap or 32 consecutive switch cells
- *   are exceeded).  Lcap >= max_depth + 4.
+ *   assertions at :108/:125 fail, FLM_AGENT_OVERFLOW when the branches before the first plain cells number
+ *   more than cap_alt, or Lcap or 32 consecutive switch cells are exceeded).  Lcap >= max_depth + 4,
+ *   cap_alt <= 64.
  * Alternatives come in the reference's order: moves left, forward, right, depth first. */
 int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const uint16_t* dist, const uint16_t* succ,
                  const int32_t* tslot, const int32_t* node_id, const int32_t* req_agent, int n_req, const int32_t* pos_cell,
