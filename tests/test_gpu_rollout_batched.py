@@ -33,13 +33,18 @@ def _rollout(fx, A, depth, max_rails, E, malfunction=None):
 
 @pytest.mark.parametrize("path", TRACES, ids=[os.path.basename(p)[:-4] for p in TRACES])
 def test_batched_rollout_replays_trace(path):
-    import torch
-    from flatland_marl_amd.rollout import hash_policy
     gold = dict(np.load(path))
     name = os.path.basename(path).split("_a")[0]
+    replay_against(load_env(name), gold)
+
+
+def replay_against(fx, gold):
+    """Drive the batched rollout with the trace driver's decisions and compare every recorded quantity."""
+    import torch
+    from flatland_marl_amd.rollout import hash_policy
     A, depth, steps, Rp = int(gold["agents"]), int(gold["depth"]), int(gold["n_steps_run"]), int(gold["max_rails"])
     E = 3
-    ro = _rollout(load_env(name), A, depth, Rp, E, malfunction_of(gold))
+    ro = _rollout(fx, A, depth, Rp, E, malfunction_of(gold))
     b = ro.b
     T1 = b.T1
     R = int(b.R[0])
