@@ -102,7 +102,8 @@ int flm_distance_bfs(const uint16_t* pred, const int32_t* cell_idx, const int32_
  *                      neither a dead end nor a target), 0xFFFF otherwise: the path walks below follow it
  *                      without distance look-ups;
  *   flm_distance_chains  dist [E,A,capCells*4] as flm_distance_bfs; ldsAnch <= capAnch is the number of
- *                      anchors the workgroup's LDS tables are sized for (80 bytes each); an environment
+ *                      anchors the workgroup's LDS tables are sized for (100 bytes each plus 16 KiB of work lists, 2047 at
+ *                      most); an environment
  *                      with more anchors is flagged in counts[e*4+3] and its rows are left unwritten. */
 int flm_target_slots(const int32_t* target_cell, int E, int A, int32_t* tslot, int32_t* n_slots, int32_t* slot_target,
                      void* stream);
