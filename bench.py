@@ -111,7 +111,7 @@ def rollout_sample(device, steps=40, workload="cfg2g", max_rails=70, rank=0, wor
                                              "speeds": "1, 1/2, 1/3, 1/4", "malfunction": malf}}
     for key, train in (("act_only", False), ("act_and_learn", True)):
         ro.reset()
-        for _ in range(3):
+        for _ in range(6):                                   # first calls size the buffers
             tr.step(train=train)
         n0, l0 = tr.n_transitions, tr.n_learn
         torch.cuda.synchronize()

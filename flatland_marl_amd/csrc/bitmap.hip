@@ -563,11 +563,13 @@ __global__ __launch_bounds__(64) void observations_req_kernel(const int8_t* __re
 }
 
 // Observation of selected agents straight from the column form: request g asks for agent req_agent[g]
-// (= e*A + a); the plane shown as its own comes from own_cols[g] when given (an alternative), else from the
-// agent's own columns; the heat planes sum the other agents' columns.  One workgroup per (1 KiB tile, request).
+// (= e*A + a); the plane shown as its own comes from own_cols when given (an alternative: row own_row[g], or
+// row g without own_row; a negative own_row means the agent's own plane), else from the agent's own columns;
+// the heat planes sum the other agents' columns.  One workgroup per (1 KiB tile, request).
 __global__ __launch_bounds__(256) void observations_req_columns_kernel(const int16_t* __restrict__ cols,
                                                                        const int32_t* __restrict__ req_agent,
-                                                                       const int16_t* __restrict__ own_cols, int A, int T1,
+                                                                       const int16_t* __restrict__ own_cols,
+                                                                       const int32_t* __restrict__ own_row, int A, int T1,
                                                                        int plane_stride, uint8_t* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) unsigned tile[3][256];   // own plane, positive heat, negative heat (packed bytes)
   const int g = blockIdx.y, tid = threadIdx.x;
@@ -587,7 +589,8 @@ __global__ __launch_bounds__(256) void observations_req_columns_kernel(const int
     const int p = (c >> 1) * T1 + t - p0;
     if (p >= 0 && p < 1024) atomicAdd(&tile[(c & 1) ? 1 : 2][p >> 2], 1u << ((p & 3) * 8));
   }
-  const int16_t* src = own_cols ? own_cols + (size_t)g * T1 : env + (size_t)a * T1;
+  const int orow = own_cols ? (own_row ? own_row[g] : g) : -1;
+  const int16_t* src = orow >= 0 ? own_cols + (size_t)orow * T1 : env + (size_t)a * T1;
   for (int t = tid; t < T1; t += 256) {
     const int c = src[t];
     if (c < 0) continue;
@@ -838,15 +841,15 @@ extern "C" int flm_observations_req(const int8_t* maps, const int32_t* req_agent
 }
 
 extern "C" int flm_observations_req_columns(const int16_t* cols, const int32_t* req_agent, const int16_t* own_cols,
-                                            int n_req, int E, int A, int Rp, int T1, int plane_stride, uint8_t* out,
-                                            void* stream) {
+                                            const int32_t* own_row, int n_req, int E, int A, int Rp, int T1,
+                                            int plane_stride, uint8_t* out, void* stream) {
   if (!cols || !req_agent || !out) return FLM_E_ARG;
   if (n_req <= 0 || n_req > 65535 || E <= 0 || A <= 0 || A > 255 || Rp <= 0 || T1 <= 0 || plane_stride % 16 != 0 ||
       (long long)plane_stride < (long long)Rp * T1)
     return FLM_E_ARG;
   dim3 grid((plane_stride + 1023) / 1024, n_req);
   hipLaunchKernelGGL(flm::observations_req_columns_kernel, grid, dim3(256), 0, (hipStream_t)stream, cols, req_agent,
-                     own_cols, A, T1, plane_stride, out);
+                     own_cols, own_row, A, T1, plane_stride, out);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }

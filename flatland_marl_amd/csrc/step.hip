@@ -514,6 +514,159 @@ __global__ __launch_bounds__(64) void env_step_kernel(
     for (int o = lane; o < A; o += 64) reward_all[base + o] = 1.0;
 }
 
+// ---- request lists and the stop/go policy on the device ---------------------------------------------------
+// The three kernels below replace what would otherwise be dozens of tiny element-wise launches per step.
+
+// Agents that consult the policy this step, in agent order: ready[] (case 1), sw[] (case 2); counts[0..1] their
+// numbers; alt_slot[g] = position of agent g in sw[] or -1; net/best cleared; the batch's view of the agents
+// (cell, heading, status) brought up to date for the path kernels.  One workgroup, every thread owns a
+// contiguous run of agents, so the lists come out ordered.
+__global__ __launch_bounds__(1024) void rollout_requests_kernel(
+    const int32_t* __restrict__ branch, const int32_t* __restrict__ status, const int32_t* __restrict__ pos,
+    const int32_t* __restrict__ heading, const int32_t* __restrict__ start_cell, int n, int32_t* __restrict__ ready,
+    int32_t* __restrict__ sw, int32_t* __restrict__ counts, int32_t* __restrict__ alt_slot, int32_t* __restrict__ net,
+    int32_t* __restrict__ best, int32_t* __restrict__ b_pos, int32_t* __restrict__ b_dir,
+    int32_t* __restrict__ b_status) {
+  __shared__ int scratch[16];
+  const int tid = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int lo = min(n, tid * per), hi = min(n, lo + per);
+  int c1 = 0, c2 = 0;
+  for (int g = lo; g < hi; g++) {
+    const int br = branch[g];
+    c1 += br == 1;
+    c2 += br == 2;
+    const int p = pos[g];
+    b_pos[g] = p >= 0 ? p : start_cell[g];
+    b_dir[g] = heading[g];
+    b_status[g] = status[g];
+    net[g] = 0;
+    best[g] = 0;
+    alt_slot[g] = -1;
+  }
+  int t1, t2;
+  int o1 = block_int_scan(c1, scratch, &t1);
+  int o2 = block_int_scan(c2, scratch, &t2);
+  for (int g = lo; g < hi; g++) {
+    const int br = branch[g];
+    if (br == 1) ready[o1++] = g;
+    if (br == 2) {
+      alt_slot[g] = o2;
+      sw[o2++] = g;
+    }
+  }
+  if (tid == 0) {
+    counts[0] = t1;
+    counts[1] = t2;
+  }
+}
+
+// After the alternatives of the n_switch agents in sw[] have been computed: an agent whose alternatives raised
+// (path or plane) is flagged in agent_err (first error kept) and left without alternatives; row_offset[i] =
+// number of alternatives of the agents before i; the rows the network evaluates are listed in row_req /
+// row_own: first the n_ready departing agents (own plane: -1), then every alternative (i*K + k) of every
+// agent of sw[]; counts[2] = number of rows.
+__global__ __launch_bounds__(1024) void rollout_alt_finish_kernel(
+    int32_t* __restrict__ alt_count, const int32_t* __restrict__ alt_err, const int32_t* __restrict__ col_err,
+    const int32_t* __restrict__ sw, int n_switch, int K, const int32_t* __restrict__ ready, int n_ready,
+    int32_t* __restrict__ agent_err, int32_t* __restrict__ row_offset, int32_t* __restrict__ row_req,
+    int32_t* __restrict__ row_own, int32_t* __restrict__ counts) {
+  __shared__ int scratch[16];
+  const int tid = threadIdx.x;
+  const int per = (n_switch + 1023) / 1024;
+  const int lo = min(n_switch, tid * per), hi = min(n_switch, lo + per);
+  int sum = 0;
+  for (int i = lo; i < hi; i++) {
+    int cnt = alt_count[i];
+    const int e0 = alt_err[i];
+    int first = e0, bad = e0 != 0;
+    int worst = 0;
+    for (int k = 0; k < K && k < cnt; k++) {
+      const int ce = col_err[i * K + k];
+      bad |= ce != 0;
+      worst = max(worst, ce);
+    }
+    if (e0 == 0) first = worst;
+    const int g = sw[i];
+    if (agent_err[g] == 0 && first != 0) agent_err[g] = first;
+    if (bad) cnt = 0;
+    alt_count[i] = cnt;
+    sum += cnt;
+  }
+  int total;
+  int off = block_int_scan(sum, scratch, &total);
+  for (int i = lo; i < hi; i++) {
+    const int cnt = alt_count[i];
+    row_offset[i] = off;
+    for (int k = 0; k < cnt; k++) {
+      row_req[n_ready + off + k] = sw[i];
+      row_own[n_ready + off + k] = i * K + k;
+    }
+    off += cnt;
+  }
+  for (int r = tid; r < n_ready; r += 1024) {
+    row_req[r] = ready[r];
+    row_own[r] = -1;
+  }
+  if (tid == 0) {
+    row_offset[n_switch] = total;
+    counts[2] = n_ready + total;
+  }
+}
+
+__device__ __forceinline__ float uniform01(uint32_t seed, uint32_t step, uint32_t g, uint32_t k) {
+  const uint32_t h = fmix32(seed ^ fmix32(step * 0x9E3779B1u + g * 0x85EBCA77u + k * 0xC2B2AE3Du + 0x165667B1u));
+  return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);     // in (0, 1): eps = 0 never explores
+}
+
+// Epsilon-greedy decisions from the Q-values of the rows listed by rollout_alt_finish_kernel
+// (src/main.py:168-172 for a departing agent, :201-208 for an agent in front of a switch: the best of all
+// (alternative, action) pairs, or with probability eps an action and an alternative drawn independently).
+// net[g] / best[g] are written for the consulting agents; sel_row / sel_act (one entry per consulting agent,
+// departing agents first) name the row whose observation the agent acted on (-1: it had no alternative) and
+// the action chosen.  Random numbers are a counter hash of (seed, step, agent).
+__global__ void policy_select_kernel(const float* __restrict__ q, const int32_t* __restrict__ ready, int n_ready,
+                                     const int32_t* __restrict__ sw, int n_switch,
+                                     const int32_t* __restrict__ row_offset, const int32_t* __restrict__ alt_count,
+                                     float eps, uint32_t seed, uint32_t step, int32_t* __restrict__ net,
+                                     int32_t* __restrict__ best, int32_t* __restrict__ sel_row,
+                                     int32_t* __restrict__ sel_act) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n_ready) {
+    const int g = ready[r];
+    int a = q[r * 2 + 1] > q[r * 2] ? 1 : 0;
+    if (uniform01(seed, step, g, 0) <= eps) a = uniform01(seed, step, g, 1) < 0.5f ? 1 : 0;
+    net[g] = a;
+    sel_row[r] = r;
+    sel_act[r] = a;
+  } else if (r < n_ready + n_switch) {
+    const int i = r - n_ready;
+    const int g = sw[i];
+    const int cnt = alt_count[i];
+    int a = 0, b = 0, row = -1;
+    if (cnt > 0) {
+      const int base = n_ready + row_offset[i];
+      float top = q[base * 2];
+      int arg = 0;
+      for (int j = 1; j < 2 * cnt; j++) {
+        const float v = q[base * 2 + j];
+        if (v > top) { top = v; arg = j; }
+      }
+      a = arg & 1;
+      b = arg >> 1;
+      if (uniform01(seed, step, g, 0) <= eps) {
+        a = uniform01(seed, step, g, 1) < 0.5f ? 1 : 0;
+        b = min((int)(uniform01(seed, step, g, 2) * cnt), cnt - 1);
+      }
+      row = base + b;
+    }
+    net[g] = a;
+    best[g] = b;
+    sel_row[r] = row;
+    sel_act[r] = a;
+  }
+}
+
 }  // namespace flm
 
 extern "C" int flm_rollout_classify(const int32_t* status, const int32_t* pos_cell, const int32_t* action_required,
@@ -569,6 +722,53 @@ extern "C" int flm_env_step(const uint16_t* grid, const int32_t* action, const i
                      init_cell, init_dir, target_cell, speed, status, pos_cell, direction, moving, fraction, exit_action,
                      done, A, H, W, reward, action_required, all_done, malfunction, malfunction_moving, env_seed,
                      malfunction_threshold, min_duration, max_duration - min_duration + 1, step_index);
+  FLM_CHECK_LAUNCH();
+  return FLM_OK;
+}
+
+extern "C" int flm_rollout_requests(const int32_t* branch, const int32_t* status, const int32_t* pos_cell,
+                                    const int32_t* direction, const int32_t* init_cell, int E, int A, int32_t* ready,
+                                    int32_t* sw, int32_t* counts, int32_t* alt_slot, int32_t* net, int32_t* best,
+                                    int32_t* batch_pos_cell, int32_t* batch_direction, int32_t* batch_status,
+                                    void* stream) {
+  if (!branch || !status || !pos_cell || !direction || !init_cell || !ready || !sw || !counts || !alt_slot || !net ||
+      !best || !batch_pos_cell || !batch_direction || !batch_status)
+    return FLM_E_ARG;
+  if (E <= 0 || A <= 0 || (long long)E * A > 0x3FFFFFFF) return FLM_E_ARG;
+  hipLaunchKernelGGL(flm::rollout_requests_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, branch, status, pos_cell,
+                     direction, init_cell, E * A, ready, sw, counts, alt_slot, net, best, batch_pos_cell, batch_direction,
+                     batch_status);
+  FLM_CHECK_LAUNCH();
+  return FLM_OK;
+}
+
+extern "C" int flm_rollout_alt_finish(int32_t* alt_count, const int32_t* alt_err, const int32_t* col_err,
+                                      const int32_t* sw, int n_switch, int cap_alt, const int32_t* ready, int n_ready,
+                                      int32_t* agent_err, int32_t* row_offset, int32_t* row_req, int32_t* row_own,
+                                      int32_t* counts, void* stream) {
+  if (!alt_count || !alt_err || !col_err || !sw || !agent_err || !row_offset || !row_req || !row_own || !counts ||
+      (n_ready > 0 && !ready))
+    return FLM_E_ARG;
+  if (n_switch <= 0 || cap_alt <= 0 || n_ready < 0 || (long long)n_switch * cap_alt + n_ready > 0x3FFFFFFF)
+    return FLM_E_ARG;
+  hipLaunchKernelGGL(flm::rollout_alt_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, alt_count, alt_err,
+                     col_err, sw, n_switch, cap_alt, ready, n_ready, agent_err, row_offset, row_req, row_own, counts);
+  FLM_CHECK_LAUNCH();
+  return FLM_OK;
+}
+
+extern "C" int flm_policy_select(const float* q, const int32_t* ready, int n_ready, const int32_t* sw, int n_switch,
+                                 const int32_t* row_offset, const int32_t* alt_count, double eps, uint32_t seed,
+                                 int step, int32_t* net, int32_t* best, int32_t* sel_row, int32_t* sel_act,
+                                 void* stream) {
+  if (!q || !net || !best || !sel_row || !sel_act || (n_ready > 0 && !ready) ||
+      (n_switch > 0 && (!sw || !row_offset || !alt_count)))
+    return FLM_E_ARG;
+  if (n_ready < 0 || n_switch < 0 || n_ready + n_switch <= 0 || step < 0) return FLM_E_ARG;
+  const int n = n_ready + n_switch;
+  hipLaunchKernelGGL(flm::policy_select_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, q, ready,
+                     n_ready, sw, n_switch, row_offset, alt_count, (float)eps, seed, (uint32_t)step, net, best, sel_row,
+                     sel_act);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }

@@ -61,11 +61,18 @@ class Dueling_DQN(nn.Module):
         return new
 
     def _workspace(self, B):
+        """Scratch floats for a forward pass of B rows.  The buffer only grows (with some headroom): rollouts
+        ask for a different B every step, and handing a buffer of a new size back and forth to the caching
+        allocator costs device allocations in the middle of the step."""
         dev = self._flat.device
-        ws = self._ws.get(B)
-        if ws is None or ws.device != dev:
-            ws = torch.empty(query("flm_dqn_forward_workspace", B, self.height), dtype=torch.float32, device=dev)
-            self._ws = {B: ws}
+        need = query("flm_dqn_forward_workspace", B, self.height)
+        ws = self._ws.get("buf")
+        if ws is None or ws.device != dev or ws.numel() < need:
+            self._ws = {}
+            ws = None                                           # release the old buffer before taking a larger one
+            grow = query("flm_dqn_forward_workspace", B + B // 4 + 1, self.height)
+            self._ws = {"buf": torch.empty(grow, dtype=torch.float32, device=dev)}
+            ws = self._ws["buf"]
         return ws
 
     def forward(self, x):

@@ -63,9 +63,13 @@ class RolloutBatch:
         self.net = torch.zeros((E, A), **i32)
         self.alt_slot = torch.full((E, A), -1, **i32)
         self.agent_err = torch.zeros((E, A), **i32)          # sticky: first error code seen for the agent
+        self.ready_list = torch.zeros((E * A,), **i32)      # agents in case 1 / case 2 this step, ascending
+        self.switch_list = torch.zeros((E * A,), **i32)
+        self.req_counts = torch.zeros((3,), **i32)           # departing agents, agents before a switch, network rows
         self._dummy_i32 = torch.zeros((1,), **i32)
         self._dummy_i16 = torch.zeros((1,), dtype=torch.int16, device=dev)
         self.cols = None
+        self._agent_flat = None
         self.t = 0
         self.malfunction = self.malfunction_moving = self.env_seed = None
         self.malf_threshold, self.malf_min, self.malf_max = 0, 0, 0
@@ -133,20 +137,21 @@ class RolloutBatch:
              self.Lp, ptr(self.branch), ptr(self.before_switch), self.stream)
         return self.branch
 
-    def alternatives(self, req):
+    def alternatives(self, req, ready=None):
         """Alternative paths and their planes (column form) for the agents req[n] (flat e*A+a, all ACTIVE):
-        get_altmaps, src/rail_observations.py:97-111."""
+        get_altmaps, src/rail_observations.py:97-111.  The batch's pos_cell / direction / status must hold
+        the agents' current state (step() sees to it).  ready: the departing agents of the same step; the
+        rows the network has to evaluate (ready first, then every alternative) are listed in row_req /
+        row_own, their number in req_counts[2]."""
         b = self.b
         n, K, dev = req.numel(), self.cap_alt, self.device
         i32 = dict(dtype=torch.int32, device=dev)
-        # the path kernels read the agents' current cell and heading from the batch
-        b.pos_cell.copy_(torch.where(self.pos >= 0, self.pos, b.start_cell))
-        b.direction.copy_(self.heading)
-        b.status.copy_(self.status)
+        n_ready = 0 if ready is None else ready.numel()
         alt = dict(count=torch.empty((n,), **i32), len=torch.zeros((n, K), **i32),
                    cell=torch.empty((n, K, self.Lp), **i32), meta=torch.empty((n, K, self.Lp), **i32),
                    err=torch.empty((n,), **i32), cols=torch.empty((n, K, b.T1), dtype=torch.int16, device=dev),
-                   col_err=torch.empty((n, K), **i32), req=req)
+                   col_err=torch.empty((n, K), **i32), req=req, row_offset=torch.empty((n + 1,), **i32),
+                   row_req=torch.empty((n_ready + n * K,), **i32), row_own=torch.empty((n_ready + n * K,), **i32))
         for lo in range(0, n, MAX_REQ):
             hi = min(n, lo + MAX_REQ)
             call("flm_altpaths", ptr(b.grid), ptr(b.cell_idx), ptr(b.dist), ptr(b.succ_table()), ptr(b.tslot), ptr(b.node_id),
@@ -154,32 +159,37 @@ class RolloutBatch:
                  hi - lo, ptr(b.pos_cell), ptr(b.direction), ptr(b.target_cell), self.E, self.A, b.H, b.W, b.cap_cells,
                  self.max_alt_depth, K, self.Lp, ptr(alt["count"][lo:hi]), ptr(alt["len"][lo:hi]), ptr(alt["cell"][lo:hi]),
                  ptr(alt["meta"][lo:hi]), ptr(alt["err"][lo:hi]), self.stream)
-        agent_flat = req.repeat_interleave(K).contiguous()
+        # one path per (request, alternative); unused alternatives have length 0
+        if self._agent_flat is None or self._agent_flat.numel() < n * K:
+            self._agent_flat = torch.empty((max(n * K, 1024),), **i32)
+        agent_flat = self._agent_flat[:n * K]
+        agent_flat.view(n, K).copy_(req[:, None].expand(n, K))
         call("flm_columns", ptr(alt["cell"]), ptr(alt["len"]), ptr(agent_flat), ptr(b.pos_cell), ptr(b.target_cell),
              ptr(b.tpc), ptr(b.node_id), ptr(b.cell_rail), ptr(b.edge_info), self.E, self.A, n * K, b.H, b.W, b.capR,
              b.Rp, b.T1, self.Lp, 0, ptr(alt["cols"]), ptr(alt["col_err"]), self.stream)
         # an alternative whose path cannot be mapped on the rail graph raises in the reference; here the agent
         # is flagged and treated as having no alternatives
-        used = torch.arange(K, device=dev)[None, :] < alt["count"][:, None]
-        bad = ((alt["col_err"] != 0) & used).any(dim=1) | (alt["err"] != 0)
-        first = torch.where(alt["err"] != 0, alt["err"], (alt["col_err"] * used).max(dim=1).values)
-        flat_err = self.agent_err.view(-1)
-        flat_err[req.long()] = torch.where(flat_err[req.long()] != 0, flat_err[req.long()], first.to(torch.int32))
-        alt["count"] = torch.where(bad, torch.zeros_like(alt["count"]), alt["count"])
+        call("flm_rollout_alt_finish", ptr(alt["count"]), ptr(alt["err"]), ptr(alt["col_err"]), ptr(req), n, K,
+             ptr(ready) if n_ready else None, n_ready, ptr(self.agent_err), ptr(alt["row_offset"]),
+             ptr(alt["row_req"]), ptr(alt["row_own"]), ptr(self.req_counts), self.stream)
         return alt
 
-    def consult_observations(self, req, own_cols=None, out=None):
+    def consult_observations(self, req, own_cols=None, out=None, own_row=None):
         """[n,3,plane_stride] uint8 observations of the agents req[n] against the current planes
-        (get_obs, src/preprocessing.py:61-74); own_cols [n,T1] replaces the planes shown as their own."""
+        (get_obs, src/preprocessing.py:61-74); own_cols replaces the planes shown as their own: row g of
+        own_cols [n,T1] for request g, or row own_row[g] of own_cols [.,T1] (negative: the agent's own)."""
         b = self.b
         n = req.numel()
         if out is None:
             out = torch.empty((n, 3, b.plane_stride), dtype=torch.uint8, device=self.device)
         for lo in range(0, n, MAX_REQ):
             hi = min(n, lo + MAX_REQ)
-            call("flm_observations_req_columns", ptr(self.cols), ptr(req[lo:hi]),
-                 ptr(own_cols[lo:hi]) if own_cols is not None else None, hi - lo, self.E, self.A, b.Rp, b.T1,
-                 b.plane_stride, ptr(out[lo:hi]), self.stream)
+            if own_row is not None:
+                oc, orow = ptr(own_cols), ptr(own_row[lo:hi])
+            else:
+                oc, orow = (ptr(own_cols[lo:hi]) if own_cols is not None else None), None
+            call("flm_observations_req_columns", ptr(self.cols), ptr(req[lo:hi]), oc, orow, hi - lo, self.E, self.A,
+                 b.Rp, b.T1, b.plane_stride, ptr(out[lo:hi]), self.stream)
         return out
 
     def apply(self, net_in, best, alt):
@@ -209,19 +219,24 @@ class RolloutBatch:
 
         policy(rollout, info) -> (net [E,A] int32: 1 = go, best [E,A] int32: chosen alternative).  info holds
         branch [E,A], req_ready (flat indices of the agents about to depart), req_switch (agents before a
-        switch), alt (their alternatives: count, len, cell, meta, cols) and t (the step number).  The policy
+        switch), alt (their alternatives: count, len, cell, meta, cols, and the rows for the network:
+        row_offset, row_req, row_own), net / best (zeroed [E,A] buffers a policy may fill and return) and t
+        (the step number).  The policy
         sees the planes as they were when the step began (src/main.py:144)."""
+        b = self.b
         self.classify()
-        flat = self.branch.view(-1)
-        req_switch = torch.nonzero(flat == 2).view(-1).to(torch.int32)
-        req_ready = torch.nonzero(flat == 1).view(-1).to(torch.int32)
-        self.alt_slot.fill_(-1)
-        alt = None
-        if req_switch.numel() > 0:
-            alt = self.alternatives(req_switch)
-            self.alt_slot.view(-1)[req_switch.long()] = torch.arange(req_switch.numel(), dtype=torch.int32,
-                                                                     device=self.device)
-        info = dict(t=self.t, branch=self.branch, req_ready=req_ready, req_switch=req_switch, alt=alt)
+        # the consulting agents (ordered lists), cleared decisions, and the batch's view of the agents
+        self._net = torch.empty((self.E, self.A), dtype=torch.int32, device=self.device)
+        self._best = torch.empty((self.E, self.A), dtype=torch.int32, device=self.device)
+        call("flm_rollout_requests", ptr(self.branch), ptr(self.status), ptr(self.pos), ptr(self.heading),
+             ptr(b.start_cell), self.E, self.A, ptr(self.ready_list), ptr(self.switch_list), ptr(self.req_counts),
+             ptr(self.alt_slot), ptr(self._net), ptr(self._best), ptr(b.pos_cell), ptr(b.direction), ptr(b.status),
+             self.stream)
+        n_ready, n_switch = self.req_counts[:2].tolist()      # the one host read-back of the step's sizes
+        req_ready, req_switch = self.ready_list[:n_ready], self.switch_list[:n_switch]
+        alt = self.alternatives(req_switch, req_ready) if n_switch else None
+        info = dict(t=self.t, branch=self.branch, req_ready=req_ready, req_switch=req_switch, alt=alt,
+                    net=self._net, best=self._best)
         net_in, best = policy(self, info)
         self.apply(net_in, best, alt)
         self.env_step()

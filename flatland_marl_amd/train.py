@@ -37,22 +37,18 @@ def obs_to_f32(obs_u8, Rp, T1, plane_stride, out=None):
 
 
 class DQNPolicy:
-    """policy(rollout, info) for RolloutBatch.step; keeps what the replay memory needs in `last`: a list of
-    (agents e*A+a, their observations as shown to the network, the actions chosen) per group of agents."""
+    """policy(rollout, info) for RolloutBatch.step: one forward pass over the observations of every departing
+    agent and of every alternative of every agent in front of a switch, then the epsilon-greedy choice on the
+    device (flm_policy_select).  `last` holds what the replay memory needs: a list with one group
+    (agents e*A+a, their observations as shown to the network, the actions chosen)."""
 
     def __init__(self, agent, eps=0.0, seed=0, chunk_bytes=2 << 30):
         self.agent = agent
         self.eps = float(eps)
         self.chunk_bytes = int(chunk_bytes)
-        self.gen = None
-        self.seed = seed
-        self.last = None
-
-    def _rand(self, n, dev):
-        if self.gen is None:
-            self.gen = torch.Generator(device=dev)
-            self.gen.manual_seed(self.seed)
-        return torch.rand(n, generator=self.gen, device=dev)
+        self.seed = int(seed) & 0xFFFFFFFF
+        self._raw = None
+        self._last = None
 
     def q_values(self, ro, obs_u8):
         b = ro.b
@@ -67,56 +63,40 @@ class DQNPolicy:
         return q
 
     def __call__(self, ro, info):
-        E, A, dev = ro.E, ro.A, ro.device
-        net = torch.zeros((E, A), dtype=torch.int32, device=dev)
-        best = torch.zeros((E, A), dtype=torch.int32, device=dev)
-        reqs, obss, acts = [], [], []
-        req1 = info["req_ready"]
-        if req1.numel():                                   # src/main.py:164-172
-            obs1 = ro.consult_observations(req1)
-            q1 = self.q_values(ro, obs1)
-            n1 = req1.numel()
-            greedy = q1.argmax(dim=1)
-            explore = self._rand(n1, dev) <= self.eps
-            coin = (self._rand(n1, dev) < 0.5).long()
-            a1 = torch.where(explore, coin, greedy)
-            net.view(-1)[req1.long()] = a1.to(torch.int32)
-            reqs.append(req1)
-            obss.append(obs1)
-            acts.append(a1)
-        alt = info["alt"]
-        if alt is not None:                                # src/main.py:193-213
-            req2 = info["req_switch"]
-            cnt = alt["count"].long()
-            K = ro.cap_alt
-            used = torch.arange(K, device=dev)[None, :] < cnt[:, None]
-            ii, kk = torch.nonzero(used, as_tuple=True)
-            if ii.numel():
-                obs2 = ro.consult_observations(req2[ii].contiguous(), alt["cols"][ii, kk].contiguous())
-                q2 = self.q_values(ro, obs2)
-                qfull = torch.full((req2.numel(), K, 2), float("-inf"), device=dev)
-                qfull[ii, kk] = q2
-                arg = qfull.view(req2.numel(), -1).argmax(dim=1)
-                g_best, g_net = arg // 2, arg % 2
-                n2 = req2.numel()
-                explore = self._rand(n2, dev) <= self.eps
-                r_net = (self._rand(n2, dev) < 0.5).long()
-                r_best = torch.minimum((self._rand(n2, dev) * cnt.clamp(min=1)).long(), cnt.clamp(min=1) - 1)
-                a2 = torch.where(explore, r_net, g_net)
-                b2 = torch.where(explore, r_best, g_best)
-                has = cnt > 0
-                net.view(-1)[req2.long()] = torch.where(has, a2, torch.zeros_like(a2)).to(torch.int32)
-                best.view(-1)[req2.long()] = torch.where(has, b2, torch.zeros_like(b2)).to(torch.int32)
-                row = torch.full((n2, K), -1, dtype=torch.long, device=dev)
-                row[ii, kk] = torch.arange(ii.numel(), device=dev)
-                sel = row[torch.arange(n2, device=dev), b2.clamp(max=K - 1)]
-                keep = has & (sel >= 0)
-                reqs.append(req2[keep])
-                obss.append(obs2[sel[keep]])
-                acts.append(a2[keep])
-        # one entry per group of consulting agents (departing, in front of a switch): (agents, observations, actions)
-        self.last = list(zip(reqs, obss, acts)) if reqs else None
+        net, best = info["net"], info["best"]
+        req1, req2, alt = info["req_ready"], info["req_switch"], info["alt"]
+        n1, n2 = req1.numel(), req2.numel()
+        self._raw = self._last = None
+        if n1 + n2 == 0:
+            return net, best
+        if alt is not None:
+            rows = int(ro.req_counts[2].item())            # departing agents + all alternatives
+            obs = ro.consult_observations(alt["row_req"][:rows], alt["cols"].view(-1, ro.b.T1), own_row=alt["row_own"][:rows]) \
+                if rows else None
+        else:
+            rows = n1
+            obs = ro.consult_observations(req1)
+        if rows == 0:                                       # agents before a switch, none with an alternative
+            return net, best
+        q = self.q_values(ro, obs)
+        sel_row = torch.empty((n1 + n2,), dtype=torch.int32, device=ro.device)
+        sel_act = torch.empty((n1 + n2,), dtype=torch.int32, device=ro.device)
+        call("flm_policy_select", ptr(q), ptr(req1) if n1 else None, n1, ptr(req2) if n2 else None, n2,
+             ptr(alt["row_offset"]) if alt is not None else None, ptr(alt["count"]) if alt is not None else None,
+             self.eps, self.seed, int(info["t"]), ptr(net), ptr(best), ptr(sel_row), ptr(sel_act), ro.stream)
+        self._raw = (req1, req2, obs, sel_row, sel_act)
         return net, best
+
+    @property
+    def last(self):
+        """[(agents, observations, actions)] of the agents that consulted the network in the last step and had
+        something to choose from (src/main.py:163-165, 194, 213), or None."""
+        if self._last is None and self._raw is not None:
+            req1, req2, obs, sel_row, sel_act = self._raw
+            req = torch.cat([req1, req2]) if req2.numel() else req1
+            ok = sel_row >= 0
+            self._last = [(req[ok], obs[sel_row[ok].long()], sel_act[ok].long())]
+        return self._last
 
 
 class DeviceReplay:
@@ -203,7 +183,7 @@ class BatchedTrainer:
         ro = self.ro
         self.policy.eps = self.eps
         ro.step(self.policy)
-        last = self.policy.last
+        last = self.policy.last if train else None
         n_new = 0
         if train and (last is not None or self.curr_obs is not None):
             dev = ro.device

@@ -177,10 +177,12 @@ int flm_observations_req(const int8_t* maps, const int32_t* req_agent, const int
                          int A, int plane_stride, uint8_t* out, void* stream);
 
 /* flm_observations_req on the column form (see flm_columns): cols [E,A,T1] int16 are the agents' planes,
- * own_cols [n_req,T1] int16 or NULL the planes shown as their own.  Same output as flm_observations_req for
- * the planes those columns describe. */
-int flm_observations_req_columns(const int16_t* cols, const int32_t* req_agent, const int16_t* own_cols, int n_req,
-                                 int E, int A, int Rp, int T1, int plane_stride, uint8_t* out, void* stream);
+ * own_cols [.,T1] int16 or NULL the planes shown as their own: row own_row[g] of own_cols for request g
+ * (own_row NULL = row g; a negative own_row[g] = the agent's own plane).  Same output as
+ * flm_observations_req for the planes those columns describe. */
+int flm_observations_req_columns(const int16_t* cols, const int32_t* req_agent, const int16_t* own_cols,
+                                 const int32_t* own_row, int n_req, int E, int A, int Rp, int T1, int plane_stride,
+                                 uint8_t* out, void* stream);
 
 /* Rail reordering of finished observations.
  * Replaces ObsPreprocessor._reorder_rails / _swap_rails, src/preprocessing.py:32-59 (enabled by
@@ -256,6 +258,33 @@ int flm_rollout_apply(int16_t* cols, const int32_t* status, const int32_t* tpc, 
                       const uint32_t* alt_meta, const int16_t* alt_cols, int32_t* path_cell, uint32_t* path_meta,
                       int32_t* path_head, int32_t* path_len, int E, int A, int W, int T1, int Lp, int cap_alt,
                       int32_t* action, int32_t* crash, int32_t* net_out, void* stream);
+
+/* Request lists and the stop/go policy on the device (the glue of src/main.py:146-213 between the cases, the
+ * alternatives, the network and the bookkeeping; no counterpart of their own in the reference).
+ *   flm_rollout_requests   ready [E*A] / sw [E*A] out: the agents (e*A + a, ascending) in case 1 / case 2 of
+ *                          branch; counts[0..1] their numbers (counts has 3 ints); alt_slot [E,A] out: position
+ *                          in sw or -1; net/best [E,A] cleared; batch_pos_cell/direction/status [E,A] out: the
+ *                          agents' cell (start cell while off the grid), heading, status for the path kernels.
+ *   flm_rollout_alt_finish after flm_altpaths + flm_columns for the n_switch agents of sw: an agent whose
+ *                          alternatives raised is flagged in agent_err [E,A] (first error kept) and its
+ *                          alt_count set to 0; row_offset [n_switch+1] out = alternatives before agent i;
+ *                          row_req / row_own [n_ready + n_switch*cap_alt] out list what the network evaluates:
+ *                          the n_ready departing agents (row_own -1), then alternative i*cap_alt + k of
+ *                          every agent; counts[2] = number of rows.
+ *   flm_policy_select      epsilon-greedy choice from q [rows,2] (src/main.py:168-172, 201-208): net/best
+ *                          [E,A] written for the consulting agents; sel_row / sel_act [n_ready + n_switch]
+ *                          out: the row each consulting agent acted on (-1 = no alternative) and its action.
+ *                          Random numbers: a counter hash of (seed, step, agent). */
+int flm_rollout_requests(const int32_t* branch, const int32_t* status, const int32_t* pos_cell,
+                         const int32_t* direction, const int32_t* init_cell, int E, int A, int32_t* ready, int32_t* sw,
+                         int32_t* counts, int32_t* alt_slot, int32_t* net, int32_t* best, int32_t* batch_pos_cell,
+                         int32_t* batch_direction, int32_t* batch_status, void* stream);
+int flm_rollout_alt_finish(int32_t* alt_count, const int32_t* alt_err, const int32_t* col_err, const int32_t* sw,
+                           int n_switch, int cap_alt, const int32_t* ready, int n_ready, int32_t* agent_err,
+                           int32_t* row_offset, int32_t* row_req, int32_t* row_own, int32_t* counts, void* stream);
+int flm_policy_select(const float* q, const int32_t* ready, int n_ready, const int32_t* sw, int n_switch,
+                      const int32_t* row_offset, const int32_t* alt_count, double eps, uint32_t seed, int step,
+                      int32_t* net, int32_t* best, int32_t* sel_row, int32_t* sel_act, void* stream);
 
 /* flm_env_step: one environment step for every environment, agents in handle order.  Stands in for
  * flatland RailEnv.step as called at src/main.py:252 (third-party, absent: restated from its published
