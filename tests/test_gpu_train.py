@@ -151,3 +151,52 @@ def test_replay_feeding_follows_the_script(s2s, penalty):
     assert total > 100
     if s2s:
         assert any(x is not None for x in buffer_obs)
+
+
+def test_policy_select_kernel():
+    """flm_policy_select against numpy: greedy choice (eps = 0) is the first maximum over (alternative, action),
+    exploring choices (eps = 1) are valid and spread out, sel_row / sel_act name the row acted on."""
+    import torch
+    from flatland_marl_amd._lib import call, ptr
+    rng = np.random.default_rng(3)
+    E, A = 6, 50
+    n = E * A
+    perm = rng.permutation(n)
+    ready = np.sort(perm[:70]).astype(np.int32)
+    sw = np.sort(perm[70:200]).astype(np.int32)
+    cnt = rng.integers(0, 5, len(sw)).astype(np.int32)
+    off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    rows = len(ready) + int(off[-1])
+    q = rng.standard_normal((rows, 2)).astype(np.float32)
+    q[5] = q[5, 0]                                             # a tie goes to action 0
+    dev = "cuda"
+    dq, dready, dsw, doff, dcnt = (torch.as_tensor(x, device=dev) for x in (q, ready, sw, off, cnt))
+    out = {}
+    for eps in (0.0, 1.0):
+        net = torch.full((n,), -7, dtype=torch.int32, device=dev)
+        best = torch.full((n,), -7, dtype=torch.int32, device=dev)
+        sel_row = torch.empty(len(ready) + len(sw), dtype=torch.int32, device=dev)
+        sel_act = torch.empty_like(sel_row)
+        call("flm_policy_select", ptr(dq), ptr(dready), len(ready), ptr(dsw), len(sw), ptr(doff), ptr(dcnt),
+             eps, 1234, 17, ptr(net), ptr(best), ptr(sel_row), ptr(sel_act), torch.cuda.current_stream().cuda_stream)
+        out[eps] = [x.cpu().numpy() for x in (net, best, sel_row, sel_act)]
+    net, best, sel_row, sel_act = out[0.0]
+    untouched = np.setdiff1d(np.arange(n), np.concatenate([ready, sw]))
+    assert (net[untouched] == -7).all() and (best[untouched] == -7).all()
+    for r, g in enumerate(ready):
+        assert net[g] == int(q[r, 1] > q[r, 0]) and sel_row[r] == r and sel_act[r] == net[g]
+    for i, g in enumerate(sw):
+        k = len(ready) + i
+        if cnt[i] == 0:
+            assert net[g] == 0 and best[g] == 0 and sel_row[k] == -1
+            continue
+        base = len(ready) + off[i]
+        arg = int(np.argmax(q[base:base + cnt[i]].reshape(-1)))
+        assert (net[g], best[g]) == (arg % 2, arg // 2)
+        assert sel_row[k] == base + best[g] and sel_act[k] == net[g]
+    net, best, sel_row, sel_act = out[1.0]
+    has = cnt > 0
+    assert set(np.unique(net[ready])) == {0, 1} and set(np.unique(net[sw[has]])) == {0, 1}
+    assert (best[sw] >= 0).all() and (best[sw][has] < cnt[has]).all() and (best[sw][~has] == 0).all()
+    assert len(np.unique(best[sw[cnt == 4]])) == 4             # every alternative gets drawn
+    assert 0.3 < net[ready].mean() < 0.7
