@@ -565,29 +565,32 @@ __global__ __launch_bounds__(64) void observations_req_kernel(const int8_t* __re
 // Observation of selected agents straight from the column form: request g asks for agent req_agent[g]
 // (= e*A + a); the plane shown as its own comes from own_cols when given (an alternative: row own_row[g], or
 // row g without own_row; a negative own_row means the agent's own plane), else from the agent's own columns;
-// the heat planes sum the other agents' columns.  One workgroup per (1 KiB tile, request).
+// the heat planes sum the other agents' columns.  One workgroup per (tile of up to 16 KiB, request): the
+// environment's A*T1 column entries are scanned once per tile, so small planes take a single scan.
+#define FLM_REQ_TILE 16384
 __global__ __launch_bounds__(256) void observations_req_columns_kernel(const int16_t* __restrict__ cols,
                                                                        const int32_t* __restrict__ req_agent,
                                                                        const int16_t* __restrict__ own_cols,
                                                                        const int32_t* __restrict__ own_row, int A, int T1,
-                                                                       int plane_stride, uint8_t* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) unsigned tile[3][256];   // own plane, positive heat, negative heat (packed bytes)
+                                                                       int plane_stride, int tile_bytes,
+                                                                       uint8_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned req_tile[];   // [3][tile_bytes/4]: own plane, positive heat, negative heat (packed bytes)
   const int g = blockIdx.y, tid = threadIdx.x;
   const int ga = req_agent[g];
   const int e = ga / A, a = ga - e * A;
-  const int p0 = blockIdx.x * 1024;
-  tile[0][tid] = 0;
-  tile[1][tid] = 0;
-  tile[2][tid] = 0;
+  const int p0 = blockIdx.x * tile_bytes;
+  const int tw = tile_bytes / 4;
+  for (int i = tid; i < 3 * tw; i += 256) req_tile[i] = 0;
   __syncthreads();
   const int16_t* env = cols + (size_t)e * A * T1;
-  for (int i = tid; i < A * T1; i += 256) {
-    const int o = i / T1, t = i - o * T1;
+  for (int o = 0; o < A; o++) {
     if (o == a) continue;
-    const int c = env[i];
-    if (c < 0) continue;
-    const int p = (c >> 1) * T1 + t - p0;
-    if (p >= 0 && p < 1024) atomicAdd(&tile[(c & 1) ? 1 : 2][p >> 2], 1u << ((p & 3) * 8));
+    for (int t = tid; t < T1; t += 256) {
+      const int c = env[o * T1 + t];
+      if (c < 0) continue;
+      const int p = (c >> 1) * T1 + t - p0;
+      if (p >= 0 && p < tile_bytes) atomicAdd(&req_tile[((c & 1) ? 1 : 2) * tw + (p >> 2)], 1u << ((p & 3) * 8));
+    }
   }
   const int orow = own_cols ? (own_row ? own_row[g] : g) : -1;
   const int16_t* src = orow >= 0 ? own_cols + (size_t)orow * T1 : env + (size_t)a * T1;
@@ -595,17 +598,15 @@ __global__ __launch_bounds__(256) void observations_req_columns_kernel(const int
     const int c = src[t];
     if (c < 0) continue;
     const int p = (c >> 1) * T1 + t - p0;
-    if (p >= 0 && p < 1024) reinterpret_cast<unsigned char*>(tile[0])[p] = (c & 1) ? (unsigned char)1 : (unsigned char)0xff;
+    if (p >= 0 && p < tile_bytes) reinterpret_cast<unsigned char*>(req_tile)[p] = (c & 1) ? (unsigned char)1 : (unsigned char)0xff;
   }
   __syncthreads();
-  if (tid < 64) {
-    const size_t off = (size_t)p0 + (size_t)tid * 16;
-    if (off < (size_t)plane_stride) {
-      uint8_t* o = out + (size_t)g * 3 * plane_stride + off;
-      *reinterpret_cast<uint4*>(o) = reinterpret_cast<const uint4*>(tile[0])[tid];
-      *reinterpret_cast<uint4*>(o + plane_stride) = reinterpret_cast<const uint4*>(tile[1])[tid];
-      *reinterpret_cast<uint4*>(o + 2 * (size_t)plane_stride) = reinterpret_cast<const uint4*>(tile[2])[tid];
-    }
+  const int n16 = min(tile_bytes, plane_stride - p0) / 16;
+  uint8_t* o = out + (size_t)g * 3 * plane_stride + p0;
+  for (int i = tid; i < n16; i += 256) {
+    reinterpret_cast<uint4*>(o)[i] = reinterpret_cast<const uint4*>(req_tile)[i];
+    reinterpret_cast<uint4*>(o + plane_stride)[i] = reinterpret_cast<const uint4*>(req_tile + tw)[i];
+    reinterpret_cast<uint4*>(o + 2 * (size_t)plane_stride)[i] = reinterpret_cast<const uint4*>(req_tile + 2 * tw)[i];
   }
 }
 
@@ -847,9 +848,10 @@ extern "C" int flm_observations_req_columns(const int16_t* cols, const int32_t* 
   if (n_req <= 0 || n_req > 65535 || E <= 0 || A <= 0 || A > 255 || Rp <= 0 || T1 <= 0 || plane_stride % 16 != 0 ||
       (long long)plane_stride < (long long)Rp * T1)
     return FLM_E_ARG;
-  dim3 grid((plane_stride + 1023) / 1024, n_req);
-  hipLaunchKernelGGL(flm::observations_req_columns_kernel, grid, dim3(256), 0, (hipStream_t)stream, cols, req_agent,
-                     own_cols, own_row, A, T1, plane_stride, out);
+  const int tile = plane_stride < FLM_REQ_TILE ? plane_stride : FLM_REQ_TILE;      // a multiple of 16
+  dim3 grid((plane_stride + tile - 1) / tile, n_req);
+  hipLaunchKernelGGL(flm::observations_req_columns_kernel, grid, dim3(256), 3 * (size_t)tile, (hipStream_t)stream, cols,
+                     req_agent, own_cols, own_row, A, T1, plane_stride, tile, out);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }

@@ -63,6 +63,16 @@ def test_full_size_workload(name, n_sample):
     torch.cuda.synchronize()
     assert _checksum(obs) == c0
 
+    # 2b. the per-request kernel (rollouts) writes the same bytes as the sweep, also on planes of many tiles
+    from flatland_marl_amd._lib import call, ptr
+    req = torch.as_tensor(np.random.default_rng(5).choice(E * A, size=min(97, E * A), replace=False).astype(np.int32),
+                          device=obs.device)
+    one = torch.empty((req.numel(), 3, ps), dtype=torch.uint8, device=obs.device)
+    call("flm_observations_req_columns", ptr(b.cols), ptr(req), None, None, req.numel(), E, A, Rp, T1, ps, ptr(one),
+         b.stream.cuda_stream)
+    assert torch.equal(one, obs.view(E * A, 3, ps)[req.long()])
+    del one
+
     # 3. sampled environments against the CPU checker: planes, heat maps, paths, errors
     rng = np.random.default_rng(7)
     names = {"": 0, "IndexError": 2, "KeyError": 3, "AssertionError": 4}
