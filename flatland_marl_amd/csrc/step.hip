@@ -519,23 +519,19 @@ __global__ __launch_bounds__(64) void env_step_kernel(
 
 // Agents that consult the policy this step, in agent order: ready[] (case 1), sw[] (case 2); counts[0..1] their
 // numbers; alt_slot[g] = position of agent g in sw[] or -1; net/best cleared; the batch's view of the agents
-// (cell, heading, status) brought up to date for the path kernels.  One workgroup, every thread owns a
-// contiguous run of agents, so the lists come out ordered.
-__global__ __launch_bounds__(1024) void rollout_requests_kernel(
+// (cell, heading, status) brought up to date for the path kernels.  Two launches over one thread per agent:
+// the first counts the two kinds per workgroup (blk[2*b], blk[2*b+1]), the second places every agent after
+// the agents of the workgroups before its own, so the lists come out ordered.
+__global__ __launch_bounds__(1024) void rollout_requests_count_kernel(
     const int32_t* __restrict__ branch, const int32_t* __restrict__ status, const int32_t* __restrict__ pos,
-    const int32_t* __restrict__ heading, const int32_t* __restrict__ start_cell, int n, int32_t* __restrict__ ready,
-    int32_t* __restrict__ sw, int32_t* __restrict__ counts, int32_t* __restrict__ alt_slot, int32_t* __restrict__ net,
-    int32_t* __restrict__ best, int32_t* __restrict__ b_pos, int32_t* __restrict__ b_dir,
-    int32_t* __restrict__ b_status) {
+    const int32_t* __restrict__ heading, const int32_t* __restrict__ start_cell, int n, int32_t* __restrict__ blk,
+    int32_t* __restrict__ alt_slot, int32_t* __restrict__ net, int32_t* __restrict__ best, int32_t* __restrict__ b_pos,
+    int32_t* __restrict__ b_dir, int32_t* __restrict__ b_status) {
   __shared__ int scratch[16];
-  const int tid = threadIdx.x;
-  const int per = (n + 1023) / 1024;
-  const int lo = min(n, tid * per), hi = min(n, lo + per);
-  int c1 = 0, c2 = 0;
-  for (int g = lo; g < hi; g++) {
-    const int br = branch[g];
-    c1 += br == 1;
-    c2 += br == 2;
+  const int g = blockIdx.x * 1024 + threadIdx.x;
+  int br = -1;
+  if (g < n) {
+    br = branch[g];
     const int p = pos[g];
     b_pos[g] = p >= 0 ? p : start_cell[g];
     b_dir[g] = heading[g];
@@ -545,19 +541,40 @@ __global__ __launch_bounds__(1024) void rollout_requests_kernel(
     alt_slot[g] = -1;
   }
   int t1, t2;
-  int o1 = block_int_scan(c1, scratch, &t1);
-  int o2 = block_int_scan(c2, scratch, &t2);
-  for (int g = lo; g < hi; g++) {
-    const int br = branch[g];
-    if (br == 1) ready[o1++] = g;
-    if (br == 2) {
-      alt_slot[g] = o2;
-      sw[o2++] = g;
-    }
+  block_flag_scan(br == 1, scratch, &t1);
+  block_flag_scan(br == 2, scratch, &t2);
+  if (threadIdx.x == 0) {
+    blk[2 * blockIdx.x] = t1;
+    blk[2 * blockIdx.x + 1] = t2;
   }
-  if (tid == 0) {
-    counts[0] = t1;
-    counts[1] = t2;
+}
+
+__global__ __launch_bounds__(1024) void rollout_requests_fill_kernel(const int32_t* __restrict__ branch, int n,
+                                                                     const int32_t* __restrict__ blk,
+                                                                     int32_t* __restrict__ ready, int32_t* __restrict__ sw,
+                                                                     int32_t* __restrict__ counts,
+                                                                     int32_t* __restrict__ alt_slot) {
+  __shared__ int scratch[16];
+  const int g = blockIdx.x * 1024 + threadIdx.x;
+  int s1 = 0, s2 = 0;
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += 1024) {
+    s1 += blk[2 * b];
+    s2 += blk[2 * b + 1];
+  }
+  int base1, base2, t1, t2;
+  block_int_scan(s1, scratch, &base1);
+  block_int_scan(s2, scratch, &base2);
+  const int br = g < n ? branch[g] : -1;
+  const int r1 = block_flag_scan(br == 1, scratch, &t1);
+  const int r2 = block_flag_scan(br == 2, scratch, &t2);
+  if (br == 1) ready[base1 + r1] = g;
+  if (br == 2) {
+    sw[base2 + r2] = g;
+    alt_slot[g] = base2 + r2;
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    counts[0] = base1 + t1;
+    counts[1] = base2 + t2;
   }
 }
 
@@ -730,14 +747,18 @@ extern "C" int flm_rollout_requests(const int32_t* branch, const int32_t* status
                                     const int32_t* direction, const int32_t* init_cell, int E, int A, int32_t* ready,
                                     int32_t* sw, int32_t* counts, int32_t* alt_slot, int32_t* net, int32_t* best,
                                     int32_t* batch_pos_cell, int32_t* batch_direction, int32_t* batch_status,
-                                    void* stream) {
+                                    int32_t* workspace, void* stream) {
   if (!branch || !status || !pos_cell || !direction || !init_cell || !ready || !sw || !counts || !alt_slot || !net ||
-      !best || !batch_pos_cell || !batch_direction || !batch_status)
+      !best || !batch_pos_cell || !batch_direction || !batch_status || !workspace)
     return FLM_E_ARG;
   if (E <= 0 || A <= 0 || (long long)E * A > 0x3FFFFFFF) return FLM_E_ARG;
-  hipLaunchKernelGGL(flm::rollout_requests_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, branch, status, pos_cell,
-                     direction, init_cell, E * A, ready, sw, counts, alt_slot, net, best, batch_pos_cell, batch_direction,
+  const int n = E * A, nb = (n + 1023) / 1024;
+  hipLaunchKernelGGL(flm::rollout_requests_count_kernel, dim3(nb), dim3(1024), 0, (hipStream_t)stream, branch, status,
+                     pos_cell, direction, init_cell, n, workspace, alt_slot, net, best, batch_pos_cell, batch_direction,
                      batch_status);
+  FLM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(flm::rollout_requests_fill_kernel, dim3(nb), dim3(1024), 0, (hipStream_t)stream, branch, n, workspace,
+                     ready, sw, counts, alt_slot);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }

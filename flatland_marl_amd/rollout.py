@@ -66,6 +66,7 @@ class RolloutBatch:
         self.ready_list = torch.zeros((E * A,), **i32)      # agents in case 1 / case 2 this step, ascending
         self.switch_list = torch.zeros((E * A,), **i32)
         self.req_counts = torch.zeros((3,), **i32)           # departing agents, agents before a switch, network rows
+        self._req_ws = torch.zeros((2 * ((E * A + 1023) // 1024),), **i32)
         self._dummy_i32 = torch.zeros((1,), **i32)
         self._dummy_i16 = torch.zeros((1,), dtype=torch.int16, device=dev)
         self.cols = None
@@ -231,7 +232,7 @@ class RolloutBatch:
         call("flm_rollout_requests", ptr(self.branch), ptr(self.status), ptr(self.pos), ptr(self.heading),
              ptr(b.start_cell), self.E, self.A, ptr(self.ready_list), ptr(self.switch_list), ptr(self.req_counts),
              ptr(self.alt_slot), ptr(self._net), ptr(self._best), ptr(b.pos_cell), ptr(b.direction), ptr(b.status),
-             self.stream)
+             ptr(self._req_ws), self.stream)
         n_ready, n_switch = self.req_counts[:2].tolist()      # the one host read-back of the step's sizes
         req_ready, req_switch = self.ready_list[:n_ready], self.switch_list[:n_switch]
         alt = self.alternatives(req_switch, req_ready) if n_switch else None

@@ -264,7 +264,8 @@ int flm_rollout_apply(int16_t* cols, const int32_t* status, const int32_t* tpc, 
  *   flm_rollout_requests   ready [E*A] / sw [E*A] out: the agents (e*A + a, ascending) in case 1 / case 2 of
  *                          branch; counts[0..1] their numbers (counts has 3 ints); alt_slot [E,A] out: position
  *                          in sw or -1; net/best [E,A] cleared; batch_pos_cell/direction/status [E,A] out: the
- *                          agents' cell (start cell while off the grid), heading, status for the path kernels.
+ *                          agents' cell (start cell while off the grid), heading, status for the path kernels;
+ *                          workspace: 2*ceil(E*A/1024) int32.
  *   flm_rollout_alt_finish after flm_altpaths + flm_columns for the n_switch agents of sw: an agent whose
  *                          alternatives raised is flagged in agent_err [E,A] (first error kept) and its
  *                          alt_count set to 0; row_offset [n_switch+1] out = alternatives before agent i;
@@ -278,7 +279,7 @@ int flm_rollout_apply(int16_t* cols, const int32_t* status, const int32_t* tpc, 
 int flm_rollout_requests(const int32_t* branch, const int32_t* status, const int32_t* pos_cell,
                          const int32_t* direction, const int32_t* init_cell, int E, int A, int32_t* ready, int32_t* sw,
                          int32_t* counts, int32_t* alt_slot, int32_t* net, int32_t* best, int32_t* batch_pos_cell,
-                         int32_t* batch_direction, int32_t* batch_status, void* stream);
+                         int32_t* batch_direction, int32_t* batch_status, int32_t* workspace, void* stream);
 int flm_rollout_alt_finish(int32_t* alt_count, const int32_t* alt_err, const int32_t* col_err, const int32_t* sw,
                            int n_switch, int cap_alt, const int32_t* ready, int n_ready, int32_t* agent_err,
                            int32_t* row_offset, int32_t* row_req, int32_t* row_own, int32_t* counts, void* stream);
