@@ -49,3 +49,21 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("no oracle", ""), os.path.join(dirpath, f)
+
+
+def test_entry_points_reject_null_and_zero_arguments():
+    """Every launching entry point checks its arguments on the host before it touches the device: with null
+    pointers and zero sizes it returns FLM_E_ARG (no GPU needed, nothing is launched)."""
+    from flatland_marl_amd import _lib
+    lib = _lib.load()
+    skip = {"flm_abi_version"} | set(_lib._LONG_RESULT)
+    checked = 0
+    for name, argtypes in _lib._SIGNATURES.items():
+        if name in skip:
+            continue
+        args = [None if t is ctypes.c_void_p else t(0) for t in argtypes]
+        assert getattr(lib, name)(*args) == -1, name
+        checked += 1
+    assert checked >= 25
+    # size queries answer 0 or a positive count, never garbage, for degenerate sizes
+    assert lib.flm_dqn_param_count(300, 151) == 19673091
