@@ -232,15 +232,30 @@ __global__ void reduce_bias_relu_kernel(const float* __restrict__ part, int nz, 
 }
 
 // column sums: out[n] = sum_m X[m*ld + n], one workgroup per 64 columns, fixed summation order
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int N, long ld, float* __restrict__ out) {
-  __shared__ float s[4][64];
-  const int n = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
-  float acc = 0.f;
-  if (n < N)
-    for (int m = w; m < M; m += 4) acc += X[(long)m * ld + n];
-  s[w][threadIdx.x & 63] = acc;
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ X, int M, int N, long ld, float* __restrict__ out) {
+  __shared__ float s[16][64];
+  const int lane = threadIdx.x & 63, n = blockIdx.x * 64 + lane, w = threadIdx.x >> 6;
+  // 16 waves split the rows; four independent partial sums per lane keep four loads in flight; every
+  // partial sum and their combination have a fixed order
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (n < N) {
+    int m = w;
+    for (; m + 48 < M; m += 64) {
+      a0 += X[(long)m * ld + n];
+      a1 += X[(long)(m + 16) * ld + n];
+      a2 += X[(long)(m + 32) * ld + n];
+      a3 += X[(long)(m + 48) * ld + n];
+    }
+    for (; m < M; m += 16) a0 += X[(long)m * ld + n];
+  }
+  s[w][lane] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (w == 0 && n < N) out[n] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+  if (w == 0 && n < N) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc += s[i][lane];
+    out[n] = acc;
+  }
 }
 
 // conv bias gradient: out[c] = sum over b,h of dX1[b][c][h]
@@ -766,7 +781,7 @@ extern "C" int flm_dqn_learn_grads(const float* local, const float* target, cons
     g.A = dhid + st * 512; g.B = x1; g.C = grads + (st ? L.v1_w : L.a1_w);
     g.M = 512; g.N = (int)L.K1; g.K = B; g.lda = 1024; g.ldb = L.K1; g.ldc = L.K1;
     if ((rc = flm::launch_gemm<false, false, flm::EPI_PLAIN>(g, 1, stream))) return rc;
-    hipLaunchKernelGGL(flm::colsum_kernel, dim3(8), dim3(256), 0, stream, dhid + st * 512, B, 512, 1024L,
+    hipLaunchKernelGGL(flm::colsum_kernel, dim3(8), dim3(1024), 0, stream, dhid + st * 512, B, 512, 1024L,
                        grads + (st ? L.v1_b : L.a1_b));
   }
   // gradient w.r.t. the conv activations: dx1 = dhid_adv * W_adv + dhid_val * W_val, zero where x1 == 0
