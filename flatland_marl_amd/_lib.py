@@ -47,6 +47,8 @@ _SIGNATURES = {
     "flm_dqn_param_count": [_i, _i],
     "flm_dqn_forward_workspace": [_i, _i],
     "flm_dqn_learn_workspace": [_i, _i, _i],
+    "flm_dqn_learn_workspace_u8": [_i, _i, _i],
+    "flm_dqn_learn_grads_u8": [_p, _p, _p, _p, _i, _p, _p, _p, C.c_float, _i, _i, _i, _p, _p, _p, _p],
     "flm_dqn_forward": [_p, _p, _i, _i, _i, _p, _p, _p],
     "flm_obs_to_f32": [_p, _i, _i, _i, _i, _p, _p],
     "flm_dqn_forward_u8": [_p, _p, _i, _i, _i, _i, _p, _p, _p],
@@ -55,7 +57,8 @@ _SIGNATURES = {
     "flm_dqn_soft_update": [_p, _p, C.c_long, C.c_double, _p],
 }
 
-_LONG_RESULT = {"flm_dqn_param_count", "flm_dqn_forward_workspace", "flm_dqn_learn_workspace"}
+_LONG_RESULT = {"flm_dqn_param_count", "flm_dqn_forward_workspace", "flm_dqn_learn_workspace",
+                "flm_dqn_learn_workspace_u8"}
 _lib = None
 
 

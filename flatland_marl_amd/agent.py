@@ -121,6 +121,36 @@ class DQNAgent:
         self.last_loss = loss
         self.soft_update(self.qnetwork_local, self.qnetwork_target, self.args.tau)
 
+    def learn_obs(self, experiences, gamma, plane_stride):
+        """learn() on uint8 observations [B,3,plane_stride] (plane 0 int8, heat planes uint8) as a device replay
+        memory stores them: same update, no float copies of the next states."""
+        states, actions, rewards, next_states, dones = experiences
+        B = states.size(0)
+        if self.height % 3:
+            raise ValueError("observations have three planes: the network height must be 3*max_rails")
+        Rp = self.height // 3
+        local = self.qnetwork_local.flat_params()
+        target = self.qnetwork_target.flat_params()
+        dev = local.device
+        n_ws = query("flm_dqn_learn_workspace_u8", B, Rp, self.width)
+        if self._ws is None or self._ws.numel() < n_ws or self._ws.device != dev:
+            self._ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
+        s, sn = states.contiguous(), next_states.contiguous()
+        if s.dtype != torch.uint8 or sn.dtype != torch.uint8 or s.shape[1:] != (3, plane_stride) or s.shape != sn.shape:
+            raise ValueError("uint8 observations [B,3,plane_stride] expected")
+        a = actions.to(dev, torch.int64).contiguous()
+        r = rewards.to(dev, torch.float32).contiguous()
+        d = dones.to(dev, torch.float32).contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        self.optimizer.zero_grad()
+        call("flm_dqn_learn_grads_u8", ptr(local), ptr(target), ptr(s), ptr(sn), int(plane_stride), ptr(a), ptr(r), ptr(d),
+             float(gamma), B, Rp, self.width, ptr(self._ws), ptr(self.optimizer.grads), ptr(loss),
+             torch.cuda.current_stream(dev).cuda_stream)
+        parallel.allreduce_mean_(self.optimizer.grads)      # data parallel: one bucket, RCCL over xGMI
+        self.optimizer.step()
+        self.last_loss = loss
+        self.soft_update(self.qnetwork_local, self.qnetwork_target, self.args.tau)
+
     def soft_update(self, local_model, target_model, tau):
         local, target = local_model.flat_params(), target_model.flat_params()
         call("flm_dqn_soft_update", ptr(target), ptr(local), local.numel(), float(tau),

@@ -743,13 +743,14 @@ extern "C" long flm_dqn_learn_workspace(int B, int H3, int T1) {
 }
 
 // Forward passes, loss and backward of one learn step (src/agent.py:94-114); grads gets dLoss/dparams of
-// the local network in the flat layout, loss_out the scalar mean-squared error.
-extern "C" int flm_dqn_learn_grads(const float* local, const float* target, const float* s, const float* s_next,
-                                   const int64_t* action, const float* reward, const float* done, float gamma, int B,
-                                   int H3, int T1, float* ws, float* grads, float* loss_out, void* stream_) {
-  if (!local || !target || !s || !s_next || !action || !reward || !done || !ws || !grads || !loss_out) return FLM_E_ARG;
-  if (B <= 0 || H3 <= 0 || T1 <= 0) return FLM_E_ARG;
-  hipStream_t stream = (hipStream_t)stream_;
+// the local network in the flat layout, loss_out the scalar mean-squared error.  Inputs are either float
+// states (s, s_next) or uint8 observations (s_u8, sn_u8 with plane_stride): then the three forward passes read
+// the bytes and s points at workspace that receives the float copy of the states the convolution's weight
+// gradient needs.
+static int learn_grads_impl(const float* local, const float* target, const float* s, const float* s_next,
+                            const uint8_t* s_u8, const uint8_t* sn_u8, int plane_stride, const int64_t* action,
+                            const float* reward, const float* done, float gamma, int B, int H3, int T1, float* ws,
+                            float* grads, float* loss_out, hipStream_t stream) {
   DqnLayout L(H3, T1);
   const long n_x1 = (long)B * 64 * H3, n_hid = (long)B * 1024;
   float* x1 = ws;            float* hid = x1 + n_x1;
@@ -763,9 +764,16 @@ extern "C" int flm_dqn_learn_grads(const float* local, const float* target, cons
   float* qn = q + 2 * B; float* qt = qn + 2 * B; float* dq = qt + 2 * B;
   float* dadv = dq + 2 * B; float* dval = dadv + 2 * B; float* sq = dval + B;
   int rc;
-  if ((rc = dqn_forward_impl(local, s, nullptr, 0, B, H3, T1, x1, hid, part, q, stream))) return rc;
-  if ((rc = dqn_forward_impl(local, s_next, nullptr, 0, B, H3, T1, x1n, hidn, part, qn, stream))) return rc;
-  if ((rc = dqn_forward_impl(target, s_next, nullptr, 0, B, H3, T1, x1t, hidt, part, qt, stream))) return rc;
+  if (s_u8) {
+    hipLaunchKernelGGL(flm::obs_to_f32_kernel, dim3(2048), dim3(256), 0, stream, s_u8, B, H3 / 3, T1, plane_stride,
+                       const_cast<float*>(s));
+    if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
+  }
+  if ((rc = dqn_forward_impl(local, s_u8 ? nullptr : s, s_u8, plane_stride, B, H3, T1, x1, hid, part, q, stream))) return rc;
+  if ((rc = dqn_forward_impl(local, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, x1n, hidn, part, qn, stream)))
+    return rc;
+  if ((rc = dqn_forward_impl(target, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, x1t, hidt, part, qt, stream)))
+    return rc;
   hipLaunchKernelGGL(flm::td_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, q, qn, qt, action, reward, done, gamma,
                      B, dq, sq);
   hipLaunchKernelGGL(flm::mean_kernel, dim3(1), dim3(64), 0, stream, sq, B, loss_out);
@@ -807,6 +815,31 @@ extern "C" int flm_dqn_learn_grads(const float* local, const float* target, cons
   }
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
+}
+
+extern "C" int flm_dqn_learn_grads(const float* local, const float* target, const float* s, const float* s_next,
+                                   const int64_t* action, const float* reward, const float* done, float gamma, int B,
+                                   int H3, int T1, float* ws, float* grads, float* loss_out, void* stream) {
+  if (!local || !target || !s || !s_next || !action || !reward || !done || !ws || !grads || !loss_out) return FLM_E_ARG;
+  if (B <= 0 || H3 <= 0 || T1 <= 0) return FLM_E_ARG;
+  return learn_grads_impl(local, target, s, s_next, nullptr, nullptr, 0, action, reward, done, gamma, B, H3, T1, ws, grads,
+                          loss_out, (hipStream_t)stream);
+}
+
+extern "C" long flm_dqn_learn_workspace_u8(int B, int Rp, int T1) {
+  return flm_dqn_learn_workspace(B, 3 * Rp, T1) + (long)B * 3 * Rp * T1;
+}
+
+extern "C" int flm_dqn_learn_grads_u8(const float* local, const float* target, const uint8_t* s, const uint8_t* s_next,
+                                      int plane_stride, const int64_t* action, const float* reward, const float* done,
+                                      float gamma, int B, int Rp, int T1, float* ws, float* grads, float* loss_out,
+                                      void* stream) {
+  if (!local || !target || !s || !s_next || !action || !reward || !done || !ws || !grads || !loss_out) return FLM_E_ARG;
+  if (B <= 0 || Rp <= 0 || T1 <= 0 || (long)plane_stride < (long)Rp * T1) return FLM_E_ARG;
+  const int H3 = 3 * Rp;
+  float* s_f32 = ws + flm_dqn_learn_workspace(B, H3, T1);     // the float copy of s lives behind the common workspace
+  return learn_grads_impl(local, target, s_f32, nullptr, s, s_next, plane_stride, action, reward, done, gamma, B, H3, T1, ws,
+                          grads, loss_out, (hipStream_t)stream);
 }
 
 extern "C" int flm_dqn_adam(float* params, const float* grads, float* m, float* v, long n, double lr, double beta1,

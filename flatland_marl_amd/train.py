@@ -172,11 +172,7 @@ class BatchedTrainer:
 
     def _learn(self):
         b = self.ro.b
-        s, a, r, sn, d = self.replay.sample(self.agent.args.batch_size)
-        B = s.shape[0]
-        sf = obs_to_f32(s.contiguous(), b.Rp, b.T1, b.plane_stride).view(B, 1, 3 * b.Rp, b.T1)
-        snf = obs_to_f32(sn.contiguous(), b.Rp, b.T1, b.plane_stride).view(B, 1, 3 * b.Rp, b.T1)
-        self.agent.learn((sf, a, r, snf, d), self.agent.args.gamma)
+        self.agent.learn_obs(self.replay.sample(self.agent.args.batch_size), self.agent.args.gamma, b.plane_stride)
         self.n_learn += 1
 
     def step(self, train=True):

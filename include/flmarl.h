@@ -338,6 +338,14 @@ int flm_dqn_learn_grads(const float* local, const float* target, const float* s,
                         const int64_t* action, const float* reward, const float* done, float gamma, int B, int H3,
                         int T1, float* workspace, float* grads, float* loss_out, void* stream);
 
+/* The same learn step on uint8 observations [B,3,plane_stride] as stored by a device replay memory: the
+ * forward passes read the bytes; only the states s are expanded to float (inside the workspace) for the
+ * convolution's weight gradient.  workspace: flm_dqn_learn_workspace_u8(B,Rp,T1) floats. */
+long flm_dqn_learn_workspace_u8(int B, int Rp, int T1);
+int flm_dqn_learn_grads_u8(const float* local, const float* target, const uint8_t* s, const uint8_t* s_next,
+                           int plane_stride, const int64_t* action, const float* reward, const float* done, float gamma,
+                           int B, int Rp, int T1, float* workspace, float* grads, float* loss_out, void* stream);
+
 /* torch.optim.Adam step with default options over flat buffers (src/agent.py:38,113-115); step counts from 1. */
 int flm_dqn_adam(float* params, const float* grads, float* m, float* v, long n, double lr, double beta1, double beta2,
                  double eps, int step, void* stream);

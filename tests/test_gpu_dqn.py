@@ -175,3 +175,43 @@ def test_forward_from_uint8_observations_vs_torch(B, Rp, T1, pad):
     want = ref(x).detach().numpy()
     got = agent.qnetwork_local.forward_obs(obs.cuda(), ps).cpu().numpy()
     assert close(got, want)
+
+
+def test_learn_from_uint8_observations_matches_float_learn():
+    """flm_dqn_learn_grads_u8 (bytes in, as the device replay memory stores them) against flm_dqn_learn_grads on
+    the float expansion of the same observations: loss and every gradient within 1e-5 relative."""
+    import types
+    import torch
+    from flatland_marl_amd.agent import DQNAgent
+    from flatland_marl_amd._lib import call, ptr, query
+    Rp, T1, B = 37, 61, 96
+    ps = 2304                                                  # > Rp*T1 = 2257, a multiple of 256
+    args = types.SimpleNamespace(prediction_depth=T1 - 1, lr=5e-5, buffer_size=10, batch_size=B, update_every=10,
+                                 gamma=0.99, tau=1e-3)
+    torch.manual_seed(1)
+    agent = DQNAgent(args, action_space=2, bitmap_height=3 * Rp)
+    g = torch.Generator().manual_seed(2)
+    obs = torch.zeros((2, B, 3, ps), dtype=torch.uint8)
+    obs[:, :, 0, :Rp * T1] = torch.randint(-1, 2, (2, B, Rp * T1), generator=g).to(torch.int8).view(torch.uint8)
+    obs[:, :, 1:, :Rp * T1] = torch.randint(0, 4, (2, B, 2, Rp * T1), generator=g).to(torch.uint8)
+    obs = obs.cuda()
+    f = torch.empty((2, B, 3 * Rp, T1), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for k in range(2):
+        call("flm_obs_to_f32", ptr(obs[k]), B, Rp, T1, ps, ptr(f[k]), st)
+    act = torch.randint(0, 2, (B,), generator=g).cuda()
+    rew = torch.randn(B, generator=g).cuda()
+    done = (torch.rand(B, generator=g) < 0.2).float().cuda()
+    local, target = agent.qnetwork_local.flat_params(), agent.qnetwork_target.flat_params()
+    target.mul_(1.01)                                           # make the two networks differ
+    grads = torch.zeros((2, local.numel()), device="cuda")
+    loss = torch.zeros((2, 1), device="cuda")
+    ws = torch.empty(query("flm_dqn_learn_workspace_u8", B, Rp, T1), device="cuda")
+    call("flm_dqn_learn_grads", ptr(local), ptr(target), ptr(f[0]), ptr(f[1]), ptr(act), ptr(rew), ptr(done), 0.99, B,
+         3 * Rp, T1, ptr(ws), ptr(grads[0]), ptr(loss[0]), st)
+    call("flm_dqn_learn_grads_u8", ptr(local), ptr(target), ptr(obs[0]), ptr(obs[1]), ps, ptr(act), ptr(rew), ptr(done),
+         0.99, B, Rp, T1, ptr(ws), ptr(grads[1]), ptr(loss[1]), st)
+    torch.cuda.synchronize()
+    assert torch.allclose(loss[0], loss[1], rtol=1e-5)
+    scale = grads[0].abs().max().item()
+    assert scale > 0 and (grads[0] - grads[1]).abs().max().item() <= 1e-5 * scale
