@@ -183,10 +183,11 @@ class ObservationBatch:
             self.chain_edges = torch.empty((E, self.cap_anchor, 4), **i32)
             self.n_anchor = torch.empty((E,), **i32)
             self.chain_succ = torch.empty((E, capS), dtype=torch.int16, device=dev)
+            self.chain_choice = torch.empty((E, capS, 4), dtype=torch.int16, device=dev)
         call("flm_target_slots", ptr(self.target_cell), E, A, ptr(self.tslot), ptr(self.n_slots), ptr(self.slot_target), s)
         call("flm_chain_index", ptr(self.grid), ptr(self.cell_idx), ptr(self.n_cells), ptr(self.target_cell), E, A,
              self.H, self.W, self.cap_cells, self.cap_anchor, ptr(self.chain_root), ptr(self.chain_steps),
-             ptr(self.chain_edges), ptr(self.n_anchor), ptr(self.counts), ptr(self.chain_succ), s)
+             ptr(self.chain_edges), ptr(self.n_anchor), ptr(self.counts), ptr(self.chain_succ), ptr(self.chain_choice), s)
         self._succ_valid = True
         if getattr(self, "lds_anchor", None) is None:
             # anchors = states with a choice of moves (fixed by the grid) + states on target cells (<= 4*A).
@@ -206,6 +207,11 @@ class ObservationBatch:
         """Forced-move table of the chain index (None after a breadth-first distance computation)."""
         return self.chain_succ if getattr(self, "_succ_valid", False) else None
 
+    def choice_table(self):
+        """Per state without a forced successor the states its moves lead to (written with the successor table), or
+        None."""
+        return self.chain_choice if getattr(self, "_succ_valid", False) else None
+
     def shortest_paths(self, max_depth=None, start_cell=None, start_dir=None):
         """get_shortest_paths for every agent (src/utils/shortest_path.py:11-90)."""
         E, A, dev = self.E, self.A, self.device
@@ -219,7 +225,8 @@ class ObservationBatch:
             path_len = torch.empty((E, A), dtype=torch.int32, device=dev)
         sc = self.pos_cell if start_cell is None else start_cell
         sd = self.direction if start_dir is None else start_dir
-        call("flm_shortest_paths", ptr(self.grid), ptr(self.cell_idx), ptr(self.dist), ptr(self.succ_table()), ptr(self.tslot), ptr(sc),
+        call("flm_shortest_paths", ptr(self.grid), ptr(self.cell_idx), ptr(self.dist), ptr(self.succ_table()),
+             ptr(self.choice_table()), ptr(self.tslot), ptr(sc),
              ptr(sd), ptr(self.target_cell), ptr(self.status), E, A, self.H, self.W, self.cap_cells, max_depth, Lcap,
              ptr(path_cell), ptr(path_meta), ptr(path_len), self.stream.cuda_stream)
         self.path_cell, self.path_meta, self.path_len, self.Lcap = path_cell, path_meta, path_len, Lcap
@@ -321,7 +328,8 @@ class ObservationBatch:
             cell=torch.empty((n, cap_alt, Lcap), dtype=torch.int32, device=dev),
             meta=torch.empty((n, cap_alt, Lcap), dtype=torch.int32, device=dev),
             err=torch.empty((n,), dtype=torch.int32, device=dev), req=req, Lcap=Lcap, cap_alt=cap_alt)
-        call("flm_altpaths", ptr(self.grid), ptr(self.cell_idx), ptr(self.dist), ptr(self.succ_table()), ptr(self.tslot), ptr(self.node_id),
+        call("flm_altpaths", ptr(self.grid), ptr(self.cell_idx), ptr(self.dist), ptr(self.succ_table()),
+             ptr(self.choice_table()), ptr(self.tslot), ptr(self.node_id),
              ptr(req), n, ptr(self.pos_cell), ptr(self.direction), ptr(self.target_cell), self.E, self.A, self.H,
              self.W, self.cap_cells, int(max_depth), cap_alt, Lcap, ptr(out["count"]), ptr(out["len"]),
              ptr(out["cell"]), ptr(out["meta"]), ptr(out["err"]), self.stream.cuda_stream)

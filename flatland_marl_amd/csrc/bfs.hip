@@ -133,7 +133,7 @@ __global__ __launch_bounds__(1024) void distance_bfs_kernel(const uint16_t* __re
 
 __global__ void shortest_paths_kernel(const uint16_t* __restrict__ grid_all, const int32_t* __restrict__ cell_idx_all,
                                       const uint16_t* __restrict__ dist_all, const uint16_t* __restrict__ succ_all,
-                                      const int32_t* __restrict__ tslot,
+                                      const uint16_t* __restrict__ choice_all, const int32_t* __restrict__ tslot,
                                       const int32_t* __restrict__ start_cell, const int32_t* __restrict__ start_dir,
                                       const int32_t* __restrict__ target_cell, const int32_t* __restrict__ status, int E,
                                       int A, int H, int W, int capCells, int max_depth, int Lcap,
@@ -153,7 +153,8 @@ __global__ void shortest_paths_kernel(const uint16_t* __restrict__ grid_all, con
   int32_t* pc = path_cell + (size_t)g * Lcap;
   uint32_t* pm = path_meta + (size_t)g * Lcap;
   const uint16_t* succ = succ_all ? succ_all + (size_t)e * capCells * 4 : nullptr;
-  path_len[g] = greedy_path(grid, cell_idx, dist, succ, H, W, start_cell[g], start_dir[g] & 3, target_cell[g], max_depth, pc,
+  const uint16_t* choice = succ_all && choice_all ? choice_all + (size_t)e * capCells * 16 : nullptr;
+  path_len[g] = greedy_path(grid, cell_idx, dist, succ, choice, H, W, start_cell[g], start_dir[g] & 3, target_cell[g], max_depth, pc,
                             pm, Lcap);
 }
 
@@ -210,7 +211,8 @@ extern "C" int flm_target_slots(const int32_t* target_cell, int E, int A, int32_
 }
 
 extern "C" int flm_shortest_paths(const uint16_t* grid, const int32_t* cell_idx, const uint16_t* dist,
-                                  const uint16_t* succ, const int32_t* tslot, const int32_t* start_cell, const int32_t* start_dir,
+                                  const uint16_t* succ, const uint16_t* choice, const int32_t* tslot,
+                                  const int32_t* start_cell, const int32_t* start_dir,
                                   const int32_t* target_cell, const int32_t* status, int E, int A, int H, int W,
                                   int capCells, int max_depth, int Lcap, int32_t* path_cell, uint32_t* path_meta,
                                   int32_t* path_len, void* stream) {
@@ -220,7 +222,7 @@ extern "C" int flm_shortest_paths(const uint16_t* grid, const int32_t* cell_idx,
   if (E <= 0 || A <= 0 || H <= 0 || W <= 0 || capCells <= 0 || max_depth < 0 || Lcap < max_depth + 1) return FLM_E_ARG;
   int total = E * A;
   hipLaunchKernelGGL(flm::shortest_paths_kernel, dim3((total + 127) / 128), dim3(128), 0, (hipStream_t)stream, grid,
-                     cell_idx, dist, succ, tslot, start_cell, start_dir, target_cell, status, E, A, H, W, capCells,
+                     cell_idx, dist, succ, choice, tslot, start_cell, start_dir, target_cell, status, E, A, H, W, capCells,
                      max_depth, Lcap, path_cell, path_meta, path_len);
   FLM_CHECK_LAUNCH();
   return FLM_OK;

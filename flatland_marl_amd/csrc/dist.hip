@@ -27,11 +27,12 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 }
 
-__global__ __launch_bounds__(1024) void chain_index_kernel(
+__global__ __launch_bounds__(1024, 8) void chain_index_kernel(
     const uint16_t* __restrict__ grid_all, const int32_t* __restrict__ cell_idx_all,
     const int32_t* __restrict__ n_cells_all, const int32_t* __restrict__ target_cell, int A, int H, int W, int capCells,
     int capAnch, uint16_t* __restrict__ root_all, uint16_t* __restrict__ steps_all, uint32_t* __restrict__ edges_all,
-    int32_t* __restrict__ n_anchor_all, int32_t* __restrict__ counts_all, uint16_t* __restrict__ succ_all) {
+    int32_t* __restrict__ n_anchor_all, int32_t* __restrict__ counts_all, uint16_t* __restrict__ succ_all,
+    uint16_t* __restrict__ choice_all) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int e = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
   const int HW = H * W;
@@ -67,6 +68,14 @@ __global__ __launch_bounds__(1024) void chain_index_kernel(
     if (ci < 0) continue;
     const int r = cell / W, c = cell - r * W;
     const unsigned code = grid[cell];
+    int nbr[4];   // compact number of the rail cell on each side some heading may leave through, -1 = none
+    const unsigned exits = (code | (code >> 4) | (code >> 8) | (code >> 12)) & 0xFu;
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+      const int nr = r + dr(n), nc = c + dc(n);
+      nbr[n] = (has_exit(exits, n) && nr >= 0 && nr < H && nc >= 0 && nc < W) ? cell_idx[nr * W + nc] : -1;
+    }
+    const bool dead_end = __popc(code & 0xFFFFu) == 1;
 #pragma unroll
     for (int h = 0; h < 4; h++) {
       const int s = ci * 4 + h;
@@ -74,13 +83,9 @@ __global__ __launch_bounds__(1024) void chain_index_kernel(
       int deg = 0, nxt = 0;
 #pragma unroll
       for (int n = 0; n < 4; n++) {
-        if (!has_exit(nib, n)) continue;
-        const int nr = r + dr(n), nc = c + dc(n);
-        if (nr < 0 || nr >= H || nc < 0 || nc >= W) continue;
-        const int ni = cell_idx[nr * W + nc];
-        if (ni < 0) continue;
+        if (!has_exit(nib, n) || nbr[n] < 0) continue;
         deg++;
-        nxt = ni * 4 + n;
+        nxt = nbr[n] * 4 + n;
       }
       const bool is_target = (flags[s >> 5] >> (s & 31)) & 1;
       if (deg >= 2 && !is_target) atomicOr(&flags[s >> 5], 1u << (s & 31));
@@ -89,6 +94,25 @@ __global__ __launch_bounds__(1024) void chain_index_kernel(
       // rail cell, and the cell is neither a dead end nor a target
       // (staged in the anchor-number array, which is not in use yet, and copied out with coalesced stores)
       aidx[s] = (!is_target && deg == 1 && __popc(nib) == 1 && __popc(code & 0xFFFFu) != 1) ? (uint16_t)nxt : (uint16_t)FLM_NONE16;
+      if (choice_all && aidx[s] == FLM_NONE16) {
+        // (only where the walk has no forced successor: it never looks at the other entries)
+        // the moves a path walk may take from this state (get_valid_move_actions_: left, forward, right; in a
+        // dead end only the U-turn, which counts as forward) and the states they lead to
+        unsigned slot[3] = {FLM_NONE16, FLM_NONE16, FLM_NONE16};
+        if (dead_end) {
+          const int ex = (h + 2) & 3;
+          if (has_exit(nib, ex) && nbr[ex] >= 0) slot[1] = (unsigned)(nbr[ex] * 4 + ex);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            const int d = (h + i + 3) & 3;                      // heading h-1, h, h+1
+            if (has_exit(nib, d) && nbr[d] >= 0) slot[i] = (unsigned)(nbr[d] * 4 + d);
+          }
+        }
+        const unsigned single = (dead_end || __popc(nib) == 1) ? 1u : 0u;
+        *reinterpret_cast<uint2*>(choice_all + ((size_t)e * capS + s) * 4) =
+            make_uint2(slot[0] | (slot[1] << 16), slot[2] | (single << 16));
+      }
       if (anchor || deg == 0) {
         jmp0[s] = (uint16_t)s;   // fixed point: anchors end a chain, dead states lead nowhere
         stp0[s] = 0;
@@ -438,7 +462,7 @@ __global__ __launch_bounds__(FLM_DC_THREADS) void distance_chain_kernel(
 extern "C" int flm_chain_index(const uint16_t* grid, const int32_t* cell_idx, const int32_t* n_cells,
                                const int32_t* target_cell, int E, int A, int H, int W, int capCells, int capAnch,
                                uint16_t* root, uint16_t* steps, uint32_t* edges, int32_t* n_anchor, int32_t* counts,
-                               uint16_t* succ, void* stream) {
+                               uint16_t* succ, uint16_t* choice, void* stream) {
   if (!grid || !cell_idx || !n_cells || !target_cell || !root || !steps || !edges || !n_anchor || !counts) return FLM_E_ARG;
   if (E <= 0 || A <= 0 || H <= 0 || W <= 0 || capCells <= 0 || capCells * 4 >= 65535 || capAnch <= 0 || capAnch > 0xFFF0)
     return FLM_E_ARG;
@@ -449,7 +473,7 @@ extern "C" int flm_chain_index(const uint16_t* grid, const int32_t* cell_idx, co
                           (int)lds) != hipSuccess)
     return FLM_E_LAUNCH;
   hipLaunchKernelGGL(flm::chain_index_kernel, dim3(E), dim3(1024), lds, (hipStream_t)stream, grid, cell_idx, n_cells,
-                     target_cell, A, H, W, capCells, capAnch, root, steps, edges, n_anchor, counts, succ);
+                     target_cell, A, H, W, capCells, capAnch, root, steps, edges, n_anchor, counts, succ, choice);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }

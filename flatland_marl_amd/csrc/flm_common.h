@@ -99,9 +99,14 @@ __device__ __forceinline__ int block_int_scan(int v, int* scratch, int* total) {
 // state that move leads to (0xFFFF otherwise).  Such a step needs no distance look-up: on a reachable
 // state the single successor is one move closer, so the walk follows succ and only evaluates candidates
 // where there is a choice.
+// choice (optional, with succ): per state four uint16: the states the moves left, forward, right lead to
+// (0xFFFF = no such move) and a flag "the move is reported as forward" (a single exit, or the U-turn of a
+// dead end, which sits in the forward slot).  With it a step with a choice reads one table entry and the
+// candidates' distances instead of the cell code and the state numbers of the neighbouring cells.
 __device__ __forceinline__ int greedy_path(const uint16_t* __restrict__ grid, const int32_t* __restrict__ cell_idx,
-                                           const uint16_t* __restrict__ dist, const uint16_t* __restrict__ succ, int H, int W,
-                                           int cell, int h, int tcell, int max_depth, int32_t* pc, uint32_t* pm, int cap) {
+                                           const uint16_t* __restrict__ dist, const uint16_t* __restrict__ succ,
+                                           const uint16_t* __restrict__ choice, int H, int W, int cell, int h, int tcell,
+                                           int max_depth, int32_t* pc, uint32_t* pm, int cap) {
   unsigned best_d = 0xFFFFFFFFu;
   int n = 0, depth = 0;
   int s = -1;                 // compact state number of (cell, h) while it is known
@@ -154,6 +159,32 @@ __device__ __forceinline__ int greedy_path(const uint16_t* __restrict__ grid, co
         best_d -= 1;
         continue;
       }
+    }
+    if (choice && s >= 0) {
+      const uint2 raw = *reinterpret_cast<const uint2*>(choice + (size_t)s * 4);
+      const unsigned ns[3] = {raw.x & 0xFFFFu, raw.x >> 16, raw.y & 0xFFFFu};
+      int best = -1;
+      unsigned best_s = 0;
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        if (ns[i] == 0xFFFFu) continue;
+        const unsigned dd = dist[ns[i]];
+        if (dd != FLM_DIST_INF && dd < best_d) {
+          best = i;
+          best_d = dd;
+          best_s = ns[i];
+        }
+      }
+      if (best < 0) return -1;
+      const int nd1 = (int)(best_s & 3u);
+      const unsigned action = (raw.y >> 16) & 1u ? 2u : (unsigned)(1 + best);
+      emit(cell, (unsigned)h | (action << 8) | ((unsigned)nd1 << 16));
+      depth++;
+      cell += dr(nd1) * W + dc(nd1);
+      h = nd1;
+      s = (int)best_s;
+      reach = true;
+      continue;
     }
     int r = cell / W, c = cell - r * W;
     int act[3], nd[3];

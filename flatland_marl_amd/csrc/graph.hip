@@ -58,7 +58,7 @@ __device__ Walk walk_rail(const uint16_t* grid, const NodeT* node_id, int H, int
 // LDS_GRID: the transition codes and the node numbers of the environment are staged in LDS (2 + 2 bytes per
 // cell), so that the rail walks, chains of dependent look-ups, run at LDS latency.
 template <bool LDS_GRID>
-__global__ __launch_bounds__(1024) void graph_build_kernel(
+__global__ __launch_bounds__(1024, 8) void graph_build_kernel(
     const uint16_t* __restrict__ grid_all, int H, int W, int capN, int capR, int capC, int32_t* __restrict__ node_id_all,
     int32_t* __restrict__ node_cell_all, int32_t* __restrict__ edge_info_all, int32_t* __restrict__ edge_cell_off_all,
     int32_t* __restrict__ edge_cells_all, int32_t* __restrict__ cell_rail_all, int32_t* __restrict__ counts_all) {

@@ -15,7 +15,8 @@ namespace flm {
 
 __global__ __launch_bounds__(64) void altpaths_kernel(
     const uint16_t* __restrict__ grid_all, const int32_t* __restrict__ cell_idx_all,
-    const uint16_t* __restrict__ dist_all, const uint16_t* __restrict__ succ_all, const int32_t* __restrict__ tslot,
+    const uint16_t* __restrict__ dist_all, const uint16_t* __restrict__ succ_all,
+    const uint16_t* __restrict__ choice_all, const int32_t* __restrict__ tslot,
     const int32_t* __restrict__ node_id_all, const int32_t* __restrict__ req_agent, int n_req,
     const int32_t* __restrict__ pos_cell, const int32_t* __restrict__ direction,
     const int32_t* __restrict__ target_cell, int A, int H, int W, int capCells, int max_depth, int cap_alt, int Lcap,
@@ -33,6 +34,7 @@ __global__ __launch_bounds__(64) void altpaths_kernel(
   const int32_t* node_id = node_id_all + (size_t)e * HW;
   const uint16_t* dist = dist_all + ((size_t)e * A + tslot[ga]) * capCells * 4;
   const uint16_t* succ = succ_all ? succ_all + (size_t)e * capCells * 4 : nullptr;
+  const uint16_t* choice = succ_all && choice_all ? choice_all + (size_t)e * capCells * 16 : nullptr;
   const int tcell = target_cell[ga];
   int32_t* out_len = alt_len + (size_t)g * cap_alt;
   int32_t* slot_cell = alt_cell + (size_t)g * cap_alt * Lcap;
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(64) void altpaths_kernel(
       if (start == -1) {
         res = base;
       } else if (start >= 0) {
-        const int n = greedy_path(grid, cell_idx, dist, succ, H, W, start, s_h[lane], tcell, max_depth,
+        const int n = greedy_path(grid, cell_idx, dist, succ, choice, H, W, start, s_h[lane], tcell, max_depth,
                                   slot_cell + (size_t)j * Lcap + base, slot_meta + (size_t)j * Lcap + base, Lcap - base);
         if (n >= 0) res = base + n > Lcap ? -2 : base + n;
       }
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(256) void update_bitmaps_kernel(int8_t* __restrict_
 }  // namespace flm
 
 extern "C" int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const uint16_t* dist, const uint16_t* succ,
-                            const int32_t* tslot, const int32_t* node_id, const int32_t* req_agent, int n_req, const int32_t* pos_cell,
+                            const uint16_t* choice, const int32_t* tslot, const int32_t* node_id, const int32_t* req_agent, int n_req, const int32_t* pos_cell,
                             const int32_t* direction, const int32_t* target_cell, int E, int A, int H, int W,
                             int capCells, int max_depth, int cap_alt, int Lcap, int32_t* alt_count, int32_t* alt_len,
                             int32_t* alt_cell, uint32_t* alt_meta, int32_t* err, void* stream) {
@@ -351,7 +353,7 @@ extern "C" int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const
   while (G < cap_alt) G *= 2;
   const int per_block = 64 / G;
   hipLaunchKernelGGL(flm::altpaths_kernel, dim3((n_req + per_block - 1) / per_block), dim3(64), 0, (hipStream_t)stream,
-                     grid, cell_idx, dist, succ, tslot, node_id, req_agent, n_req, pos_cell, direction, target_cell, A, H, W,
+                     grid, cell_idx, dist, succ, choice, tslot, node_id, req_agent, n_req, pos_cell, direction, target_cell, A, H, W,
                      capCells, max_depth, cap_alt, Lcap, G, alt_count, alt_len, alt_cell, alt_meta, err);
   FLM_CHECK_LAUNCH();
   return FLM_OK;

@@ -100,7 +100,11 @@ int flm_distance_bfs(const uint16_t* pred, const int32_t* cell_idx, const int32_
  *                      flm_state_index and the agents' target cells; succ [E,capCells*4] uint16 (may be NULL)
  *                      out: the state a forced move leads to (one exit in the heading's transitions, the cell
  *                      neither a dead end nor a target), 0xFFFF otherwise: the path walks below follow it
- *                      without distance look-ups;
+ *                      without distance look-ups; choice [E,capCells*4,4] uint16 (may be NULL) out: per state
+ *                      the states its moves left, forward, right lead to (0xFFFF = no such move; the U-turn of
+ *                      a dead end sits in the forward slot) and 1 when the move is reported as forward
+ *                      (src/utils/shortest_path.py:56-57 through get_valid_move_actions_), so that a walk reads
+ *                      one entry where it has a choice; written only for states whose succ is 0xFFFF;
  *   flm_distance_chains  dist [E,A,capCells*4] as flm_distance_bfs; ldsAnch <= capAnch is the number of
  *                      anchors the workgroup's LDS tables are sized for (100 bytes each plus 16 KiB of work lists, 2047 at
  *                      most); an environment
@@ -109,7 +113,7 @@ int flm_target_slots(const int32_t* target_cell, int E, int A, int32_t* tslot, i
                      void* stream);
 int flm_chain_index(const uint16_t* grid, const int32_t* cell_idx, const int32_t* n_cells, const int32_t* target_cell,
                     int E, int A, int H, int W, int capCells, int capAnch, uint16_t* root, uint16_t* steps,
-                    uint32_t* edges, int32_t* n_anchor, int32_t* counts, uint16_t* succ, void* stream);
+                    uint32_t* edges, int32_t* n_anchor, int32_t* counts, uint16_t* succ, uint16_t* choice, void* stream);
 int flm_distance_chains(const uint16_t* root, const uint16_t* steps, const uint32_t* edges, const int32_t* n_anchor,
                         const int32_t* n_cells, const int32_t* cell_idx, const int32_t* slot_target,
                         const int32_t* n_slots, int E, int A, int H, int W, int capCells, int capAnch, int ldsAnch,
@@ -121,9 +125,10 @@ int flm_distance_chains(const uint16_t* root, const uint16_t* steps, const uint3
  *   path_cell [E,A,Lcap] int32, path_meta [E,A,Lcap] uint32 = heading | action<<8 | next heading<<16
  *   (next cell = cell + move(next heading), or the same cell when action == 4)
  *   path_len  [E,A] int32, -1 = None.  Lcap >= max_depth + 1.
- *   succ: the table written by flm_chain_index for the same targets, or NULL (same paths, more look-ups). */
+ *   succ, choice: the tables written by flm_chain_index for the same targets, or NULL (same paths, more
+ *   look-ups; choice is only used together with succ). */
 int flm_shortest_paths(const uint16_t* grid, const int32_t* cell_idx, const uint16_t* dist, const uint16_t* succ,
-                       const int32_t* tslot, const int32_t* start_cell, const int32_t* start_dir,
+                       const uint16_t* choice, const int32_t* tslot, const int32_t* start_cell, const int32_t* start_dir,
                        const int32_t* target_cell, const int32_t* status, int E, int A, int H, int W,
                        int capCells, int max_depth, int Lcap, int32_t* path_cell, uint32_t* path_meta,
                        int32_t* path_len, void* stream);
@@ -205,7 +210,7 @@ int flm_reorder_rails(const uint8_t* obs_in, uint8_t* obs_out, int n, int Rp, in
  *   cap_alt <= 64.
  * Alternatives come in the reference's order: moves left, forward, right, depth first. */
 int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const uint16_t* dist, const uint16_t* succ,
-                 const int32_t* tslot, const int32_t* node_id, const int32_t* req_agent, int n_req, const int32_t* pos_cell,
+                 const uint16_t* choice, const int32_t* tslot, const int32_t* node_id, const int32_t* req_agent, int n_req, const int32_t* pos_cell,
                  const int32_t* direction, const int32_t* target_cell, int E, int A, int H, int W, int capCells,
                  int max_depth, int cap_alt, int Lcap, int32_t* alt_count, int32_t* alt_len, int32_t* alt_cell,
                  uint32_t* alt_meta, int32_t* err, void* stream);
