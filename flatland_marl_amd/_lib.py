@@ -55,6 +55,8 @@ _SIGNATURES = {
     "flm_dqn_learn_grads": [_p, _p, _p, _p, _p, _p, _p, C.c_float, _i, _i, _i, _p, _p, _p, _p],
     "flm_dqn_adam": [_p, _p, _p, _p, C.c_long, C.c_double, C.c_double, C.c_double, C.c_double, _i, _p],
     "flm_dqn_soft_update": [_p, _p, C.c_long, C.c_double, _p],
+    "flm_dqn_adam_soft_update": [_p, _p, _p, _p, _p, C.c_long, C.c_double, C.c_double, C.c_double, C.c_double, _i,
+                                 C.c_double, _p],
 }
 
 _LONG_RESULT = {"flm_dqn_param_count", "flm_dqn_forward_workspace", "flm_dqn_learn_workspace",

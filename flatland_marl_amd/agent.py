@@ -42,12 +42,19 @@ class FlatAdam:
         self._ensure()
         self.grads.zero_()
 
-    def step(self):
+    def step(self, target=None, tau=None):
+        """One Adam step; with target (the target network's flat parameters) and tau also its soft update with
+        the new parameters, in the same pass."""
         flat = self._ensure()
         self.step_count += 1
-        call("flm_dqn_adam", ptr(flat), ptr(self.grads), ptr(self.m), ptr(self.v), flat.numel(), float(self.lr),
-             float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_count,
-             torch.cuda.current_stream(flat.device).cuda_stream)
+        st = torch.cuda.current_stream(flat.device).cuda_stream
+        if target is None:
+            call("flm_dqn_adam", ptr(flat), ptr(self.grads), ptr(self.m), ptr(self.v), flat.numel(), float(self.lr),
+                 float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_count, st)
+        else:
+            call("flm_dqn_adam_soft_update", ptr(flat), ptr(self.grads), ptr(self.m), ptr(self.v), ptr(target),
+                 flat.numel(), float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                 self.step_count, float(tau), st)
 
 
 class DQNAgent:
@@ -117,9 +124,8 @@ class DQNAgent:
              self.height, self.width, ptr(self._ws), ptr(self.optimizer.grads), ptr(loss),
              torch.cuda.current_stream(dev).cuda_stream)
         parallel.allreduce_mean_(self.optimizer.grads)      # data parallel: one bucket, RCCL over xGMI
-        self.optimizer.step()
         self.last_loss = loss
-        self.soft_update(self.qnetwork_local, self.qnetwork_target, self.args.tau)
+        self._update(target)
 
     def learn_obs(self, experiences, gamma, plane_stride):
         """learn() on uint8 observations [B,3,plane_stride] (plane 0 int8, heat planes uint8) as a device replay
@@ -147,9 +153,16 @@ class DQNAgent:
              float(gamma), B, Rp, self.width, ptr(self._ws), ptr(self.optimizer.grads), ptr(loss),
              torch.cuda.current_stream(dev).cuda_stream)
         parallel.allreduce_mean_(self.optimizer.grads)      # data parallel: one bucket, RCCL over xGMI
-        self.optimizer.step()
         self.last_loss = loss
-        self.soft_update(self.qnetwork_local, self.qnetwork_target, self.args.tau)
+        self._update(target)
+
+    def _update(self, target):
+        """optimizer.step() and soft_update (src/agent.py:113-118); one pass when soft_update is the class's own."""
+        if type(self).soft_update is DQNAgent.soft_update:
+            self.optimizer.step(target=target, tau=self.args.tau)
+        else:
+            self.optimizer.step()
+            self.soft_update(self.qnetwork_local, self.qnetwork_target, self.args.tau)
 
     def soft_update(self, local_model, target_model, tau):
         local, target = local_model.flat_params(), target_model.flat_params()

@@ -259,11 +259,13 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
 }
 
 // conv bias gradient: out[c] = sum over b,h of dX1[b][c][h]
+// (blockIdx.y selects one of gridDim.y interleaved parts of the batch; out[y*64 + c] are partial sums that the
+// caller adds up in a fixed order)
 __global__ __launch_bounds__(1024) void conv_bias_grad_kernel(const float* __restrict__ dX1, int B, int H3, float* __restrict__ out) {
   __shared__ float s[16];
   const int c = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float acc = 0.f;
-  for (int b = w; b < B; b += 16) {
+  for (int b = blockIdx.y * 16 + w; b < B; b += 16 * gridDim.y) {
     const float* row = dX1 + ((long)b * 64 + c) * H3;
     for (int h = lane; h < H3; h += 64) acc += row[h];
   }
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(1024) void conv_bias_grad_kernel(const float* __res
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; k++) t += s[k];
-    out[c] = t;
+    out[blockIdx.y * 64 + c] = t;
   }
 }
 
@@ -465,6 +467,24 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   v[i] = vi;
   const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2_sqrt), eps);
   p[i] = __fadd_rn(p[i], __fmul_rn(-step_size, __fdiv_rn(mi, denom)));
+}
+
+// Adam step followed by the soft update of the target network with the new parameters, in one pass
+__global__ void adam_soft_update_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                        float* __restrict__ v, float* __restrict__ target, long n, float one_minus_b1,
+                                        float beta2, float one_minus_b2, float eps, float step_size, float bc2_sqrt,
+                                        float tau, float one_minus_tau) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  const float mi = __fadd_rn(m[i], __fmul_rn(one_minus_b1, __fsub_rn(gi, m[i])));
+  const float vi = __fadd_rn(__fmul_rn(v[i], beta2), __fmul_rn(__fmul_rn(one_minus_b2, gi), gi));
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2_sqrt), eps);
+  const float pi = __fadd_rn(p[i], __fmul_rn(-step_size, __fdiv_rn(mi, denom)));
+  p[i] = pi;
+  target[i] = __fadd_rn(__fmul_rn(tau, pi), __fmul_rn(one_minus_tau, target[i]));
 }
 
 // target <- tau*local + (1-tau)*target (src/agent.py:120-131)
@@ -811,7 +831,9 @@ static int learn_grads_impl(const float* local, const float* target, const float
     const long ne = 64L * T1;
     hipLaunchKernelGGL(flm::reduce_partials_kernel, dim3((unsigned)((ne + 63) / 64)), dim3(1024), 0, stream, cpart, B, ne,
                        grads + L.conv_w);
-    hipLaunchKernelGGL(flm::conv_bias_grad_kernel, dim3(64), dim3(1024), 0, stream, dx1, B, H3, grads + L.conv_b);
+    // bias: four interleaved parts of the batch side by side (cpart is free again: stream order), then their sum
+    hipLaunchKernelGGL(flm::conv_bias_grad_kernel, dim3(64, 4), dim3(1024), 0, stream, dx1, B, H3, cpart);
+    hipLaunchKernelGGL(flm::reduce_partials_kernel, dim3(1), dim3(1024), 0, stream, cpart, 4, 64L, grads + L.conv_b);
   }
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
@@ -850,6 +872,19 @@ extern "C" int flm_dqn_adam(float* params, const float* grads, float* m, float* 
   hipLaunchKernelGGL(flm::adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads, m,
                      v, n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)(lr / bc1),
                      (float)sqrt(bc2));
+  if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
+  return FLM_OK;
+}
+
+extern "C" int flm_dqn_adam_soft_update(float* params, const float* grads, float* m, float* v, float* target, long n,
+                                        double lr, double beta1, double beta2, double eps, int step, double tau,
+                                        void* stream) {
+  if (!params || !grads || !m || !v || !target || n <= 0 || step <= 0) return FLM_E_ARG;
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  hipLaunchKernelGGL(flm::adam_soft_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     params, grads, m, v, target, n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                     (float)(lr / bc1), (float)sqrt(bc2), (float)tau, (float)(1.0 - tau));
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
 }

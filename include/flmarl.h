@@ -355,6 +355,11 @@ int flm_dqn_learn_grads_u8(const float* local, const float* target, const uint8_
 int flm_dqn_adam(float* params, const float* grads, float* m, float* v, long n, double lr, double beta1, double beta2,
                  double eps, int step, void* stream);
 
+/* flm_dqn_adam followed by flm_dqn_soft_update of target with the new parameters, in one pass over the
+ * buffers (src/agent.py:113-118): the same bits as the two calls. */
+int flm_dqn_adam_soft_update(float* params, const float* grads, float* m, float* v, float* target, long n, double lr,
+                             double beta1, double beta2, double eps, int step, double tau, void* stream);
+
 /* target <- tau*local + (1-tau)*target, src/agent.py:120-131. */
 int flm_dqn_soft_update(float* target, const float* local, long n, double tau, void* stream);
 
