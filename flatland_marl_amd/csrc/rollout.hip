@@ -12,6 +12,7 @@ namespace flm {
 // a request run side by side; last, leaves whose descent found no way are squeezed out in order.
 // More than cap_alt leaves is FLM_AGENT_OVERFLOW.
 #define FLM_ALT_STACK 32
+#define FLM_ALT_FRAME_INTS (2 * (FLM_ALT_STACK + 2) + 4 * FLM_ALT_STACK + 6 * FLM_ALT_STACK)   // per request
 
 __global__ __launch_bounds__(64) void altpaths_kernel(
     const uint16_t* __restrict__ grid_all, const int32_t* __restrict__ cell_idx_all,
@@ -23,6 +24,7 @@ __global__ __launch_bounds__(64) void altpaths_kernel(
     int G, int32_t* __restrict__ alt_count, int32_t* __restrict__ alt_len, int32_t* __restrict__ alt_cell,
     uint32_t* __restrict__ alt_meta, int32_t* __restrict__ err_out) {
   __shared__ int s_cell[64], s_h[64], s_base[64], s_res[64], s_n[64], s_err[64];
+  extern __shared__ int alt_frames[];     // [64 / G][FLM_ALT_FRAME_INTS]
   const int lane = threadIdx.x, grp = lane / G, j = lane - grp * G;
   const int g = blockIdx.x * (64 / G) + grp;
   const bool live = g < n_req;
@@ -43,11 +45,17 @@ __global__ __launch_bounds__(64) void altpaths_kernel(
 
   if (live && j == 0) {
     const int pos = pos_cell[ga], h0 = direction[ga] & 3;
-    // prefix elements (cell, meta) and DFS frames over switch cells
-    int pre_cell[FLM_ALT_STACK + 2];
-    unsigned pre_meta[FLM_ALT_STACK + 2];
-    int f_cell[FLM_ALT_STACK], f_h[FLM_ALT_STACK], f_i[FLM_ALT_STACK], f_k[FLM_ALT_STACK];
-    int f_act[FLM_ALT_STACK][3], f_nd[FLM_ALT_STACK][3];
+    // prefix elements (cell, meta) and DFS frames over switch cells: the group's slice of LDS (private arrays of
+    // this size would live in scratch memory)
+    int* frame = alt_frames + grp * FLM_ALT_FRAME_INTS;
+    int* pre_cell = frame;                                                   // [FLM_ALT_STACK + 2]
+    unsigned* pre_meta = reinterpret_cast<unsigned*>(frame + FLM_ALT_STACK + 2);   // [FLM_ALT_STACK + 2]
+    int* f_cell = frame + 2 * (FLM_ALT_STACK + 2);                           // [FLM_ALT_STACK] each
+    int* f_h = f_cell + FLM_ALT_STACK;
+    int* f_i = f_h + FLM_ALT_STACK;
+    int* f_k = f_i + FLM_ALT_STACK;
+    int(*f_act)[3] = reinterpret_cast<int(*)[3]>(f_k + FLM_ALT_STACK);        // [FLM_ALT_STACK][3] each
+    int(*f_nd)[3] = reinterpret_cast<int(*)[3]>(f_k + FLM_ALT_STACK + 3 * FLM_ALT_STACK);
     if (pos == tcell || pos < 0 || pos >= HW) {
       err = FLM_AGENT_ASSERT_ERROR;
     } else {
@@ -352,7 +360,11 @@ extern "C" int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const
   int G = 1;                              // lanes per request
   while (G < cap_alt) G *= 2;
   const int per_block = 64 / G;
-  hipLaunchKernelGGL(flm::altpaths_kernel, dim3((n_req + per_block - 1) / per_block), dim3(64), 0, (hipStream_t)stream,
+  const size_t lds = (size_t)per_block * FLM_ALT_FRAME_INTS * sizeof(int);
+  if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(flm::altpaths_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return FLM_E_LAUNCH;
+  hipLaunchKernelGGL(flm::altpaths_kernel, dim3((n_req + per_block - 1) / per_block), dim3(64), lds, (hipStream_t)stream,
                      grid, cell_idx, dist, succ, choice, tslot, node_id, req_agent, n_req, pos_cell, direction, target_cell, A, H, W,
                      capCells, max_depth, cap_alt, Lcap, G, alt_count, alt_len, alt_cell, alt_meta, err);
   FLM_CHECK_LAUNCH();
