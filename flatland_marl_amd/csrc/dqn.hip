@@ -510,143 +510,216 @@ __global__ void obs_to_f32_kernel(const uint8_t* __restrict__ obs, int n, int Rp
 
 // ---- convolution straight from uint8 observations ----------------------------------------------------
 // x1[b][c][h] = relu(bias[c] + sum_k W[c][k] * obs(b, h, k)) for the 64 filters, where row h = plane*Rp + rail
-// of an observation [3][plane_stride] (plane 0 holds int8, the heat planes uint8).  A workgroup owns 256
-// consecutive rows (b,h): their bytes (256 x T1) and the whole filter bank (T1 x 64 floats) sit in LDS, each
-// of the 4 waves multiplies 64 rows by the 64 filters on the matrix cores (2x2 tiles of 32x32), and the
-// result goes through LDS once more so that every filter's 256 outputs are stored contiguously.
-#define CV_ROWS 256
+// of an observation [3][plane_stride] (plane 0 holds int8, the heat planes uint8).
+// Workgroups are persistent, one per CU (8 waves) while the rows fit the LDS: the filter bank (T1 x 64 floats)
+// is staged in LDS once, then each wave
+// works through tiles of 64 consecutive rows (b,h) on its own, without workgroup barriers.  Per tile a wave
+//   * writes the tile's bytes, fetched into registers while the previous tile was being multiplied, into its
+//     own 64 rows of LDS (a row starts at any byte address, so its bytes keep their offset within the first
+//     word; the few bytes copied beyond the row meet zero filter weights).  Row addresses are wave-uniform and
+//     advance in scalar registers; a lane always fetches the same word of every row,
+//   * starts the loads of its next tile,
+//   * multiplies filters (matrix rows) by observation rows (matrix columns) on the matrix cores, 2x2 tiles of
+//     32x32: a lane then holds 32 filters of one observation row, and a store instruction writes 32
+//     consecutive rows of one filter, which is the layout of x1.
+#define CV_TILE 64
 #define CV_ASTRIDE(T1) ((((T1) + 6) / 4 * 4) | 4)              // bytes per row in LDS: covers 3 + T1 bytes, word count odd
 #define CV_WSTRIDE 65                                            // floats per k in LDS
-#define CV_SSTRIDE (CV_ROWS + 1)
-__global__ __launch_bounds__(256) void conv_u8_kernel(const uint8_t* __restrict__ obs, const float* __restrict__ Wc,
-                                                      const float* __restrict__ bias, long M, int Rp, int T1, int H3,
-                                                      int plane_stride, float* __restrict__ x1) {
+__device__ __forceinline__ void cv_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
+
+template <int WPL, int NWAVE>   // words a lane fetches per row (rows of up to 64*WPL words); waves per workgroup
+__global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void conv_u8_kernel(
+    const uint8_t* __restrict__ obs, const float* __restrict__ Wc, const float* __restrict__ bias, long M, int Rp, int T1,
+    int H3, int plane_stride, long obs_bytes, float* __restrict__ x1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cv_lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int astr = CV_ASTRIDE(T1);
   const int KP = (T1 + 1) & ~1;                                  // K padded to a whole MFMA step
-  unsigned char* Ab = cv_lds;                                    // [CV_ROWS][astr]
-  float* Wl = reinterpret_cast<float*>(cv_lds + (((size_t)CV_ROWS * astr + 15) & ~(size_t)15));   // [KP][CV_WSTRIDE]
-  const long m0 = (long)blockIdx.x * CV_ROWS;
-  // rows: each wave copies its own 64 rows with aligned 4-byte loads, lanes along the row.  A row starts at any
-  // byte address, so its bytes keep their offset within the first word (0..3) in LDS too; the few bytes
-  // copied beyond the row meet zero filter weights (k >= T1).
-  {
-    const int nword = (T1 + 3 + 3) >> 2;                         // words that cover any alignment of T1 bytes
-    long m = m0 + wave * 64;
-    long b = m / H3;
-    int h = (int)(m - b * H3);
-    for (int r0 = wave * 64; r0 < wave * 64 + 64; r0 += 8) {     // 8 rows in flight per pass
-      for (int wb = 0; wb < nword; wb += 64) {
-        const int w = wb + lane;
-        unsigned v[8];
-        long bb = b;
-        int hh = h;
+  const int nword = (T1 + 6) >> 2;                               // words that cover any alignment of T1 bytes
+  unsigned char* Ab = cv_lds + (size_t)wave * CV_TILE * astr;    // this wave's rows: [CV_TILE][astr]
+  float* Wl = reinterpret_cast<float*>(cv_lds + (((size_t)NWAVE * CV_TILE * astr + 15) & ~(size_t)15));   // [KP][CV_WSTRIDE]
+  float* bl = Wl + (size_t)KP * CV_WSTRIDE;                      // [64]
+  // filters, transposed to [k][c]: a wave takes 64/NWAVE filters, lanes along k, all its loads in flight
+  constexpr int FPW = 64 / NWAVE;
+  for (int kb = 0; kb < KP; kb += 64) {
+    const int k = kb + lane;
+    float v[FPW];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-          v[i] = 0;
-          if (m + i < M && w < nword) {
-            const int pl = hh / Rp, rail = hh - pl * Rp;
-            const uint8_t* src = obs + ((size_t)bb * 3 + pl) * plane_stride + (size_t)rail * T1;
-            v[i] = reinterpret_cast<const unsigned*>(src - (reinterpret_cast<size_t>(src) & 3))[w];
+    for (int ci = 0; ci < FPW; ci++) v[ci] = k < T1 ? Wc[(long)(wave * FPW + ci) * T1 + k] : 0.f;
+    if (k < KP) {
+#pragma unroll
+      for (int ci = 0; ci < FPW; ci++) Wl[k * CV_WSTRIDE + wave * FPW + ci] = v[ci];
+    }
+  }
+  if (tid < 64) bl[tid] = bias[tid];
+  __syncthreads();
+
+  const unsigned uM = (unsigned)M, uH3 = (unsigned)H3, uRp = (unsigned)Rp;      // M < 2^31 (checked by the host)
+  const unsigned NT = (uM + CV_TILE - 1) / CV_TILE;
+  const unsigned GW = gridDim.x * NWAVE;
+  // byte offsets are taken from the 4-byte aligned address at or below obs
+  const unsigned mis = (unsigned)(reinterpret_cast<size_t>(obs) & 3);
+  const uint8_t* obs_al = obs - mis;
+  const size_t end_off = ((size_t)mis + (size_t)obs_bytes + 3) & ~(size_t)3;
+  // the words of a row this lane fetches; lanes beyond the row's last word repeat that word
+  int wc[WPL];
+#pragma unroll
+  for (int x = 0; x < WPL; x++) wc[x] = min(lane + 64 * x, nword - 1);
+  unsigned pre[CV_TILE * WPL];
+  // of the tile being fetched: rows it has, element offset of its first row in x1 (both wave-uniform); per row
+  // (row = lane): byte offset within the first word | 4 if the plane is signed, and its element offset in x1
+  // relative to the first row's
+  unsigned nxt_rows = 0;
+  long nxt_out0 = 0;
+  int nxt_os = 0;
+  unsigned nxt_drel = 0;
+  auto prefetch = [&](unsigned tile) {
+    const unsigned m0 = tile * CV_TILE;
+    unsigned b = m0 / uH3;
+    const unsigned h0 = m0 - b * uH3;
+    unsigned pl = h0 / uRp, rail = h0 - pl * uRp;
+    size_t off = (size_t)mis + ((size_t)b * 3 + pl) * (size_t)plane_stride + (size_t)rail * T1;
+    nxt_rows = min((unsigned)CV_TILE, uM - m0);
+    nxt_out0 = (long)b * 64 * H3 + h0;
+    {   // this lane's row
+      const unsigned m = m0 + lane;
+      const unsigned bb = m / uH3, hh = m - bb * uH3, pp = hh / uRp, rr = hh - pp * uRp;
+      const size_t o = (size_t)mis + ((size_t)bb * 3 + pp) * (size_t)plane_stride + (size_t)rr * T1;
+      nxt_os = (int)(o & 3) | (pp == 0 ? 4 : 0);
+      nxt_drel = (bb - b) * 64u * uH3 + hh - h0;
+    }
+#pragma unroll
+    for (int j = 0; j < CV_TILE; j++) {
+      if ((unsigned)j < nxt_rows) {
+        const size_t a = off & ~(size_t)3;
+        const unsigned* src = reinterpret_cast<const unsigned*>(obs_al + a);
+        if (a + (size_t)nword * 4 <= end_off) {
+#pragma unroll
+          for (int x = 0; x < WPL; x++) pre[j * WPL + x] = src[wc[x]];
+        } else {                           // the last rows of the buffer: no word beyond its end is read
+#pragma unroll
+          for (int x = 0; x < WPL; x++) {
+            const bool ok = a + (size_t)wc[x] * 4 + 4 <= end_off;
+            pre[j * WPL + x] = src[ok ? wc[x] : 0];
           }
-          if (++hh == H3) { hh = 0; bb++; }
         }
-        if (w < nword) {
-#pragma unroll
-          for (int i = 0; i < 8; i++) reinterpret_cast<unsigned*>(Ab + (size_t)(r0 + i) * astr)[w] = v[i];
+        off += (size_t)T1;
+        if (++rail == uRp) {
+          rail = 0;
+          if (++pl == 3) { pl = 0; b++; }
+          off = (size_t)mis + ((size_t)b * 3 + pl) * (size_t)plane_stride;
         }
       }
-      m += 8;
-      h += 8;
-      while (h >= H3) { h -= H3; b++; }
     }
-  }
-  // filters, transposed to [k][c]: 8 loads in flight per thread
-  for (int i0 = 0; i0 < 64 * KP; i0 += 256 * 8) {
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int i = i0 + j * 256 + tid;
-      const int c = i / KP, k = i - c * KP;
-      v[j] = (i < 64 * KP && k < T1) ? Wc[(long)c * T1 + k] : 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int i = i0 + j * 256 + tid;
-      const int c = i / KP, k = i - c * KP;
-      if (i < 64 * KP) Wl[k * CV_WSTRIDE + c] = v[j];
-    }
-  }
-  __syncthreads();
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-  const int c32 = lane & 31, kh = lane >> 5;
-  const int row0 = wave * 64 + c32, row1 = row0 + 32;
-  // plane 0 rows are signed
-  bool sg0, sg1;
-  {
-    const long ma = m0 + row0, mb = m0 + row1;
-    sg0 = (int)(ma % H3) < Rp;
-    sg1 = (int)(mb % H3) < Rp;
-  }
-  // byte offset of the row within its first word: the row's global address modulo 4
-  auto row_off = [&](long m) {
-    const long b = m / H3;
-    const int h = (int)(m - b * H3);
-    const int pl = h / Rp, rail = h - pl * Rp;
-    return (int)((reinterpret_cast<size_t>(obs) + ((size_t)b * 3 + pl) * plane_stride + (size_t)rail * T1) & 3);
   };
-  const unsigned char* a0p = Ab + (size_t)row0 * astr + kh + row_off(m0 + row0);
-  const unsigned char* a1p = Ab + (size_t)row1 * astr + kh + row_off(m0 + row1);
+
+  const int c32 = lane & 31, kh = lane >> 5;
   const float* wp = Wl + kh * CV_WSTRIDE + c32;
-  for (int kk = 0; kk < KP; kk += 2) {
-    const unsigned u0 = a0p[kk], u1 = a1p[kk];
-    const float a0 = sg0 ? (float)(int)(signed char)u0 : (float)u0;
-    const float a1 = sg1 ? (float)(int)(signed char)u1 : (float)u1;
-    const float b0 = wp[kk * CV_WSTRIDE], b1 = wp[kk * CV_WSTRIDE + 32];
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-  }
-  __syncthreads();
-  // stage [filter][row] so that the stores run along the rows
-  float* S = reinterpret_cast<float*>(cv_lds);
+  auto stash = [&]() {   // the fetched words go to this wave's rows
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+    for (int j = 0; j < CV_TILE; j++) {
+      if ((unsigned)j < nxt_rows) {
+#pragma unroll
+        for (int x = 0; x < WPL; x++) *reinterpret_cast<unsigned*>(Ab + j * astr + wc[x] * 4) = pre[j * WPL + x];
+      }
+    }
+  };
+  // Software pipeline over this wave's tiles: while tile t is multiplied its successor's bytes are in flight;
+  // they are written to LDS right after the products, and only then are the outputs of tile t stored, so that
+  // those stores drain during the next tile's products instead of in front of a wait.
+  unsigned t = __builtin_amdgcn_readfirstlane(blockIdx.x * NWAVE + wave);
+  unsigned cur_rows = 0, cur_drel = 0;
+  long cur_out0 = 0;
+  int cur_os = 0;
+  if (t < NT) {
+    prefetch(t);
+    stash();
+    cur_rows = nxt_rows; cur_out0 = nxt_out0; cur_os = nxt_os; cur_drel = nxt_drel;
+    cv_wave_sync();
+    if (t + GW < NT) prefetch(t + GW);
+  }
+  for (; t < NT; t += GW) {
+    const int os0 = __shfl(cur_os, c32), os1 = __shfl(cur_os, c32 + 32);
+    // sign extension from bit 7 for the signed plane, from bit 8 (never set) for the others
+    const unsigned wd0 = os0 & 4 ? 8u : 9u, wd1 = os1 & 4 ? 8u : 9u;
+    const unsigned char* b0p = Ab + c32 * astr + kh + (os0 & 3);
+    const unsigned char* b1p = Ab + (c32 + 32) * astr + kh + (os1 & 3);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    auto kstep = [&](int kk) {
+      const unsigned u0 = b0p[kk], u1 = b1p[kk];
+      const float f0 = wp[kk * CV_WSTRIDE], f1 = wp[kk * CV_WSTRIDE + 32];
+      const float x0 = (float)(int)__builtin_amdgcn_sbfe((int)u0, 0u, wd0);
+      const float x1v = (float)(int)__builtin_amdgcn_sbfe((int)u1, 0u, wd1);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0, x0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0, x1v, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f1, x0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f1, x1v, acc[1][1], 0, 0, 0);
+    };
+    int kk = 0;
+    for (; kk + 8 <= KP; kk += 8) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) kstep(kk + 2 * u);
+    }
+    for (; kk < KP; kk += 2) kstep(kk);
+    cv_wave_sync();                        // every lane has read its rows before the next tile overwrites them
+    const unsigned o_rows = cur_rows;
+    const unsigned d_lane = cur_drel;
+    float* dst0 = x1 + cur_out0;
+    if (t + GW < NT) {
+      stash();
+      cur_rows = nxt_rows; cur_out0 = nxt_out0; cur_os = nxt_os; cur_drel = nxt_drel;
+      cv_wave_sync();
+      if (t + 2 * GW < NT) prefetch(t + 2 * GW);
+    }
+    // acc[i][j][r]: filter 32*i + (r&3) + 8*(r>>2) + 4*kh of observation row 32*j + c32
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-      const int c = j * 32 + c32;
-      const float bv = bias[c];
+      const unsigned d = __shfl(d_lane, c32 + 32 * j) + 4u * kh * uH3;
+      if ((unsigned)(c32 + 32 * j) < o_rows) {
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int row = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        const float v = acc[i][j][r] + bv;
-        S[c * CV_SSTRIDE + row] = v > 0.f ? v : 0.f;
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int c = 32 * i + (r & 3) + 8 * (r >> 2);
+            dst0[d + (unsigned)c * uH3] = fmaxf(acc[i][j][r] + bl[c + 4 * kh], 0.f);
+          }
       }
-    }
-  __syncthreads();
-  {
-    const long m = m0 + tid;
-    if (m < M) {
-      const long b = m / H3;
-      const int h = (int)(m - b * H3);
-      float* dst = x1 + (size_t)b * 64 * H3 + h;
-      for (int c = 0; c < 64; c++) dst[(size_t)c * H3] = S[c * CV_SSTRIDE + tid];
     }
   }
 }
 
-static size_t conv_u8_lds(int T1) {
-  const size_t a = (((size_t)CV_ROWS * CV_ASTRIDE(T1) + 15) & ~(size_t)15) + (size_t)((T1 + 1) & ~1) * CV_WSTRIDE * 4;
-  const size_t st = (size_t)64 * CV_SSTRIDE * 4;
-  return a > st ? a : st;
+static size_t conv_u8_lds(int T1, int nwave) {
+  return (((size_t)nwave * CV_TILE * CV_ASTRIDE(T1) + 15) & ~(size_t)15) + ((size_t)((T1 + 1) & ~1) * CV_WSTRIDE + 64) * 4;
+}
+
+template <int WPL, int NWAVE>
+static int launch_conv_u8(const uint8_t* obs_u8, const float* Wc, const float* bias, long M, int Rp, int T1, int H3,
+                          int plane_stride, long obs_bytes, float* x1, hipStream_t stream) {
+  const size_t lds = conv_u8_lds(T1, NWAVE);
+  if (lds > 160 * 1024 - 512) return FLM_E_ARG;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8_kernel<WPL, NWAVE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds) != hipSuccess)
+    return FLM_E_LAUNCH;
+  // persistent workgroups: one per CU (256 CUs)
+  const long tiles = (M + CV_TILE - 1) / CV_TILE;
+  long wgs = (tiles + NWAVE - 1) / NWAVE;
+  if (wgs > 256) wgs = 256;
+  if (wgs < 1) wgs = 1;
+  hipLaunchKernelGGL((conv_u8_kernel<WPL, NWAVE>), dim3((unsigned)wgs), dim3(64 * NWAVE), lds, stream, obs_u8, Wc, bias, M,
+                     Rp, T1, H3, plane_stride, obs_bytes, x1);
+  if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
+  return FLM_OK;
 }
 
 }  // namespace flm
@@ -686,15 +759,21 @@ static int dqn_forward_impl(const float* params, const float* x, const uint8_t* 
     rc = flm::launch_gemm<true, true, flm::EPI_CONV>(g, 1, stream);
     if (rc) return rc;
   } else {
-    const size_t lds = flm::conv_u8_lds(T1);
-    if (lds > 160 * 1024 - 512) return FLM_E_ARG;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flm::conv_u8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return FLM_E_LAUNCH;
     const long M = (long)B * H3;
-    hipLaunchKernelGGL(flm::conv_u8_kernel, dim3((unsigned)((M + CV_ROWS - 1) / CV_ROWS)), dim3(256), lds, stream, obs_u8,
-                       params + L.conv_w, params + L.conv_b, M, H3 / 3, T1, H3, plane_stride, x1);
-    if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
+    const long obs_bytes = (long)B * 3 * plane_stride;
+    if (M >= (1L << 31)) return FLM_E_ARG;
+    const int nword = (T1 + 6) >> 2;
+    const float* cw = params + L.conv_w;
+    const float* cb = params + L.conv_b;
+    if (nword <= 64 && flm::conv_u8_lds(T1, 8) <= 160 * 1024 - 512)        // two waves per SIMD share one filter bank
+      rc = flm::launch_conv_u8<1, 8>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
+    else if (nword <= 64)
+      rc = flm::launch_conv_u8<1, 4>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
+    else if (nword <= 128)
+      rc = flm::launch_conv_u8<2, 4>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
+    else
+      rc = FLM_E_ARG;
+    if (rc) return rc;
   }
   if (B <= 8 && (L.K1 & 3) == 0) {
     hipLaunchKernelGGL(flm::fc1_small_kernel<8>, dim3(128), dim3(256), 0, stream, x1, params + L.a1_w, params + L.a1_b, B,
