@@ -327,7 +327,8 @@ int flm_dqn_forward(const float* params, const float* x, int B, int H3, int T1, 
 
 /* The same forward pass straight from uint8 observations [n,3,plane_stride] (plane 0 int8, heat planes
  * uint8, rows of T1 bytes: what flm_observations* write): the convolution reads the bytes, no float copy
- * of the input is made.  workspace: flm_dqn_forward_workspace(n, 3*Rp) floats. */
+ * of the input is made.  workspace: flm_dqn_forward_workspace(n, 3*Rp) floats.
+ * Limits (FLM_E_ARG beyond them): n*3*Rp < 2^31 rows; T1 <= 313 (a row tile and the filter bank share the LDS). */
 int flm_dqn_forward_u8(const float* params, const uint8_t* obs, int n, int Rp, int T1, int plane_stride,
                        float* workspace, float* q, void* stream);
 
