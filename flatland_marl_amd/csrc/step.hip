@@ -49,7 +49,7 @@ __device__ __forceinline__ int rail_dir(const ColEnv& m, int a, int ts, int* dir
 
 // src/rail_observations.py:257-299: the train (other than a, already departed) that leaves `rail` last and its
 // expected exit time (0 = nobody).  Ties keep the lowest agent number.
-__device__ int wave_last_train(const ColEnv& m, int a, int rail, int* last) {
+__device__ __forceinline__ int wave_last_train(const ColEnv& m, int a, int rail, int* last) {
   const int lane = threadIdx.x;
   int key = 0;
   for (int o = lane; o < m.A; o += 64) {
@@ -78,7 +78,7 @@ __device__ int wave_last_train(const ColEnv& m, int a, int rail, int* last) {
 }
 
 // src/rail_observations.py:192-204
-__device__ bool wave_headon_crash(const ColEnv& m, int a, int rail, int dir) {
+__device__ __forceinline__ bool wave_headon_crash(const ColEnv& m, int a, int rail, int dir) {
   int last;
   const int le = wave_last_train(m, a, rail, &last);
   if (le > 0) {
@@ -91,7 +91,7 @@ __device__ bool wave_headon_crash(const ColEnv& m, int a, int rail, int dir) {
 }
 
 // src/rail_observations.py:182-190
-__device__ bool wave_cell_occupied(const ColEnv& m, int a, int cell) {
+__device__ __forceinline__ bool wave_cell_occupied(const ColEnv& m, int a, int cell) {
   bool hit = false;
   for (int o = threadIdx.x; o < m.A; o += 64)
     if (o != a && m.pos[o] == cell) hit = true;
@@ -99,7 +99,7 @@ __device__ bool wave_cell_occupied(const ColEnv& m, int a, int cell) {
 }
 
 // src/rail_observations.py:206-230.  next_cell: the cell the agent's path enters next (-1 = empty path).
-__device__ bool wave_check_crash(const ColEnv& m, int a, bool before_switch, int init_cell, int next_cell) {
+__device__ __forceinline__ bool wave_check_crash(const ColEnv& m, int a, bool before_switch, int init_cell, int next_cell) {
   if (m.status[a] == 0) {
     if (wave_cell_occupied(m, a, init_cell)) return true;
     int dir;
@@ -118,7 +118,7 @@ __device__ bool wave_check_crash(const ColEnv& m, int a, bool before_switch, int
 }
 
 // src/rail_observations.py:167-180
-__device__ void wave_delay(const ColEnv& m, int a, int rail, int dir, int delay) {
+__device__ __forceinline__ void wave_delay(const ColEnv& m, int a, int rail, int dir, int delay) {
   const int lane = threadIdx.x;
   int16_t* row = m.row(a);
   int odir;
@@ -148,7 +148,7 @@ __device__ void wave_delay(const ColEnv& m, int a, int rail, int dir, int delay)
 }
 
 // src/rail_observations.py:232-252
-__device__ void wave_update_bitmaps(const ColEnv& m, int a, bool before_switch) {
+__device__ __forceinline__ void wave_update_bitmaps(const ColEnv& m, int a, bool before_switch) {
   const int lane = threadIdx.x;
   int16_t* row = m.row(a);
   if (before_switch) {
@@ -233,6 +233,7 @@ __global__ void rollout_classify_kernel(const int32_t* __restrict__ status, cons
 // The per-agent part of one training-loop step (src/main.py:146-249) for every environment: one wave per
 // environment, agents in handle order.  net_in is the stop/go decision (1 = go) of the agents in cases 1
 // and 2; alt_slot/best pick the alternative a case-2 agent commits to.
+template <bool LDS>   // the environment's columns are staged in LDS for the walk
 __global__ __launch_bounds__(64) void rollout_apply_kernel(
     int16_t* __restrict__ cols_all, const int32_t* __restrict__ status_all, const int32_t* __restrict__ tpc_all,
     const int32_t* __restrict__ pos_all, const int32_t* __restrict__ init_all, const int32_t* __restrict__ branch_all,
@@ -242,9 +243,17 @@ __global__ __launch_bounds__(64) void rollout_apply_kernel(
     uint32_t* __restrict__ path_meta, int32_t* __restrict__ path_head, int32_t* __restrict__ path_len, int A, int W,
     int T1, int Lp, int cap_alt, int32_t* __restrict__ action_out, int32_t* __restrict__ crash_out,
     int32_t* __restrict__ net_out) {
+  extern __shared__ __attribute__((aligned(16))) int16_t s_cols[];
   const int e = blockIdx.x, lane = threadIdx.x;
-  // the environment's columns (A*T1*2 bytes) stay in global memory: they are L2-resident for the whole walk
-  ColEnv m{cols_all + (size_t)e * A * T1, A, T1, status_all + (size_t)e * A, tpc_all + (size_t)e * A,
+  // The walk over the agents is a chain of dependent look-ups in the environment's columns (A*T1*2 bytes):
+  // they are staged in LDS when they fit, otherwise they stay in global memory (L2-resident for the walk).
+  int16_t* cols_env = cols_all + (size_t)e * A * T1;
+  const int n_cols = A * T1;
+  if (LDS) {
+    for (int i = lane; i < n_cols; i += 64) s_cols[i] = cols_env[i];
+    __syncthreads();
+  }
+  ColEnv m{LDS ? s_cols : cols_env, A, T1, status_all + (size_t)e * A, tpc_all + (size_t)e * A,
            pos_all + (size_t)e * A};
   for (int a = 0; a < A; a++) {
     const size_t g = (size_t)e * A + a;
@@ -337,6 +346,8 @@ __global__ __launch_bounds__(64) void rollout_apply_kernel(
     }
     __syncthreads();
   }
+  if (LDS)
+    for (int i = lane; i < n_cols; i += 64) cols_env[i] = s_cols[i];
 }
 
 __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
@@ -714,9 +725,16 @@ extern "C" int flm_rollout_apply(int16_t* cols, const int32_t* status, const int
     return FLM_E_ARG;
   if (E <= 0 || A <= 0 || A > 4095 || W <= 0 || T1 <= 1 || T1 > 64 * FLM_STEP_KT || Lp <= 0 || cap_alt <= 0)
     return FLM_E_ARG;
-  hipLaunchKernelGGL(flm::rollout_apply_kernel, dim3(E), dim3(64), 0, (hipStream_t)stream, cols, status, tpc, pos_cell,
-                     init_cell, branch, net_in, alt_slot, best, alt_count, alt_len, alt_cell, alt_meta, alt_cols,
-                     path_cell, path_meta, path_head, path_len, A, W, T1, Lp, cap_alt, action, crash, net_out);
+  // up to 32 KiB of columns per environment go to LDS (several environments still share a CU)
+  const size_t col_bytes = ((size_t)A * T1 * sizeof(int16_t) + 15) & ~(size_t)15;
+  if (col_bytes <= 32 * 1024)
+    hipLaunchKernelGGL(flm::rollout_apply_kernel<true>, dim3(E), dim3(64), col_bytes, (hipStream_t)stream, cols, status, tpc,
+                       pos_cell, init_cell, branch, net_in, alt_slot, best, alt_count, alt_len, alt_cell, alt_meta,
+                       alt_cols, path_cell, path_meta, path_head, path_len, A, W, T1, Lp, cap_alt, action, crash, net_out);
+  else
+    hipLaunchKernelGGL(flm::rollout_apply_kernel<false>, dim3(E), dim3(64), 0, (hipStream_t)stream, cols, status, tpc,
+                       pos_cell, init_cell, branch, net_in, alt_slot, best, alt_count, alt_len, alt_cell, alt_meta,
+                       alt_cols, path_cell, path_meta, path_head, path_len, A, W, T1, Lp, cap_alt, action, crash, net_out);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }
