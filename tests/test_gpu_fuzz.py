@@ -73,6 +73,9 @@ def test_generated_environments_against_checker(case):
     (25, 25, 10, 80, 120, dict(spacing=4, max_rails=70), 11),
     (30, 44, 24, 150, 150, dict(spacing=3, keep=0.5), 12),
     (21, 21, 12, 40, 100, dict(spacing=2, keep=0.55), 13),
+    # 44 agents x 401 columns: more than the 32 KiB of columns the per-agent walk stages in LDS, so this case
+    # takes the walk that leaves them in global memory
+    (30, 44, 44, 400, 120, dict(spacing=3, keep=0.5), 17),
 ])
 def test_generated_rollout_against_checker(H, W, A, depth, steps, kw, seed):
     """A full rollout on a generated grid: the trace the CPU checker's builder produces under the trace driver
