@@ -80,7 +80,7 @@ def cpu_baseline(data, depth, Rp, budget_s=12.0, max_envs=64):
                        "C restatement of the reference algorithm (oracle/flmarl_oracle.c)" % (n_env, n_obs, dt))
 
 
-def rollout_sample(device, steps=40, workload="cfg2g", max_rails=70, rank=0, world=1):
+def rollout_sample(device, steps=40, workload="cfg2g", max_rails=70, rank=0, world=1, envs=0):
     """Environment steps per second of the batched rollout (src/main.py:142-299 for every environment at once)
     on the 1024 x 10 workload (generated 25x25 grids, max_rails = 70; the script itself pads to 100 rails,
     src/main.py:91, which --rollout-max-rails 100 reproduces): the network
@@ -94,7 +94,7 @@ def rollout_sample(device, steps=40, workload="cfg2g", max_rails=70, rank=0, wor
     from flatland_marl_amd.rollout import RolloutBatch
     from flatland_marl_amd.train import BatchedTrainer
     from flatland_marl_amd import parallel
-    data, E, A, depth, desc = workload_batch(workload, seed=1000003 * rank)
+    data, E, A, depth, desc = workload_batch(workload, envs, seed=1000003 * rank)
     b = fm.ObservationBatch(data["grid"], data["start"], data["direction"], data["target"], data["speed"], depth,
                             max_rails=max_rails, device=device)
     # episodes of <= 200 steps (src/main.py:93); malfunction process with the script's defaults (src/main.py:373-375)
@@ -131,14 +131,15 @@ def rollout_sample(device, steps=40, workload="cfg2g", max_rails=70, rank=0, wor
 def guarded_rollout_sample(out, rank, timeout_s, **kw):
     """Runs rollout_sample under a watchdog: the main JSON line must come out even if the sample stalls (a
     collective that one rank never enters).  On expiry rank 0 prints the line without the sample and every
-    rank leaves."""
+    rank leaves with exit status 3; an exception in the sample is reported in the line and makes main()
+    return 1."""
     import threading
 
     def expire():
         if rank == 0:
             out["env_steps"] = {"error": "no result within %d s" % timeout_s}
             print(json.dumps(out), flush=True)
-        os._exit(0)
+        os._exit(3)                    # a stalled sample is a failed run: the line above keeps the observation figures
     timer = threading.Timer(timeout_s, expire)
     timer.daemon = True
     timer.start()
@@ -148,6 +149,58 @@ def guarded_rollout_sample(out, rank, timeout_s, **kw):
         res = {"error": repr(ex)}
     timer.cancel()
     return res
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n_ranks, argv, timeout_s=1500.0):
+    """`python bench.py --gpus N` without an outer launcher: start N fresh processes of this script, one rank per
+    GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, relay rank 0's output and return
+    non-zero when any rank failed.  The parent never touches the GPU (no torch.cuda call, no library load), and no
+    process is replaced by another: the ranks are children."""
+    import subprocess
+    import threading
+    port = _free_port()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), FLM_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+
+    def relay():
+        for line in procs[0].stdout:
+            sys.stdout.write(line.decode(errors="replace"))
+            sys.stdout.flush()
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    t0 = time.monotonic()
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad and failed is None:
+            failed = time.monotonic()          # a rank died: the others may wait in a collective for ever
+        if (failed is not None and time.monotonic() - failed > 20.0) or time.monotonic() - t0 > timeout_s:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                   # exactly the processes started above
+        time.sleep(0.2)
+    t.join(timeout=5.0)
+    codes = [p.returncode for p in procs]
+    if any(codes):
+        sys.stderr.write("bench.py: rank exit codes %s\n" % codes)
+        return 1
+    return 0
 
 
 def main():
@@ -166,7 +219,13 @@ def main():
     ap.add_argument("--no-rollout", action="store_true", help="skip the env-steps/s sample of the batched rollout")
     ap.add_argument("--rollout-workload", default="cfg2g", choices=["cfg2", "cfg2g"])
     ap.add_argument("--rollout-max-rails", type=int, default=70)
+    ap.add_argument("--rollout-envs", type=int, default=0, help="environments per GPU of the env-steps/s sample")
+    ap.add_argument("--rollout-steps", type=int, default=40)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no outer launcher: this process only starts the ranks (before any GPU call) and waits for them
+        return launch_ranks(args.gpus, sys.argv[1:])
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -178,6 +237,11 @@ def main():
     from flatland_marl_amd import parallel
     from flatland_marl_amd.batch import plane_stride_for
     parallel.init_distributed("nccl", device)
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+    n_ranks = torch.distributed.get_world_size() if dist_on else 1     # what the collectives really span
+    backend = torch.distributed.get_backend() if dist_on else None
+    if n_ranks != max(1, args.gpus) and rank == 0:
+        sys.stderr.write("bench.py: --gpus %d but the process group has %d ranks\n" % (args.gpus, n_ranks))
 
     data, E, A, depth, desc = workload_batch(args.workload, args.envs, seed=1000003 * rank)
     # The batch is processed as `chunks` sub-batches spread over `streams` HIP streams, so that the
@@ -294,17 +358,24 @@ def main():
         total_obs = E * A * world * args.steps
         alg_bytes = 4.0 * Rp * T1 * E_launch * A   # per launch of the observation kernel
         achieved = alg_bytes / (obs_ms * 1e-3) / 1e9
+        # HBM bytes one launch really moves, from the PMC counters of a profiled run of this workload (the file
+        # names the rocprofv3 summary it was taken from and the launch shape it was measured on); the kernel
+        # writes 3 planes per agent and reads only the column form, so the figure scales with the bytes written
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "obs_kernel_traffic_%s.json" % args.workload)
         if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tfile))
+            traffic = tj.get("hbm_bytes_per_launch")
             if traffic is not None:
-                traffic = traffic * E_launch / 4096.0   # the counters were collected on a 4096-environment launch
+                measured_on = float(tj.get("E", 4096)) * tj.get("A", A) * tj.get("plane_stride", batch.plane_stride)
+                traffic = traffic * (float(E_launch) * A * batch.plane_stride) / measured_on
+        physical = None if traffic is None else traffic / (obs_ms * 1e-3) / 1e9
         out = {
             "metric": "agent-observations/sec (bitmap+heatmaps)",
             "value": total_obs / dt,
             "unit": "agent-observations/s",
-            "n_gpus": world,
+            "n_gpus": n_ranks,
+            "dist_backend": backend,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -318,6 +389,11 @@ def main():
                        "step": "graph build + distance maps + shortest paths + occupancy columns + observations (dense planes are plane 0 of each observation)"},
             "roofline": {"kernel": "observations_columns_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                         "achieved_physical": physical, "frac_physical": None if physical is None else physical / 8000.0,
+                         "note": "achieved/frac price the launch at the algorithmic 4*Rp*T1 bytes per agent-observation "
+                                 "(one plane read + three written); the kernel never reads a dense plane, so it moves "
+                                 "only `traffic` bytes (PMC): achieved_physical/frac_physical are that figure over the "
+                                 "same event-timed duration",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": obs_ms},
             "observations_only": {"value": E_launch * A / (obs_ms * 1e-3), "unit": "agent-observations/s",
                                   "note": "heat/observation sweep alone, one GPU"},
@@ -326,13 +402,15 @@ def main():
             out["cpu_baseline"] = cpu_baseline(data, depth, int(Rp))
     if not args.no_rollout:
         res = guarded_rollout_sample(out, rank, 240, device=device, workload=args.rollout_workload,
-                                     max_rails=args.rollout_max_rails, world=world)
+                                     max_rails=args.rollout_max_rails, world=world, envs=args.rollout_envs,
+                                     steps=args.rollout_steps)
         out["env_steps"] = res
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+    return 1 if isinstance(out.get("env_steps"), dict) and "error" in out["env_steps"] else 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
