@@ -122,9 +122,13 @@ def rollout_sample(device, steps=40, workload="cfg2g", max_rails=70, rank=0, wor
             tr.step(train=train)
         torch.cuda.synchronize()
         dt = parallel.max_over_ranks(time.perf_counter() - t0, device) / steps
+        flagged, overflowed = ro.flagged_agents()
         out[key] = {"value": E * world / dt, "ms_per_step": dt * 1e3,
                     "transitions_per_step": (tr.n_transitions - n0) / steps,
-                    "learn_steps_per_step": (tr.n_learn - l0) / steps}
+                    "learn_steps_per_step": (tr.n_learn - l0) / steps,
+                    "agents_flagged": flagged, "agents_over_capacity": overflowed}
+        if overflowed:
+            raise OverflowError("%d agents exceeded the rollout's alternative / path capacities" % overflowed)
     return out
 
 

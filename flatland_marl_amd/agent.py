@@ -82,9 +82,9 @@ class DQNAgent:
 
     def load(self, filename):
         if os.path.exists(filename + ".local"):
-            self.qnetwork_local.load_state_dict(torch.load(filename + ".local"))
+            self.qnetwork_local.load_state_dict(torch.load(filename + ".local", weights_only=True))
         if os.path.exists(filename + ".target"):
-            self.qnetwork_target.load_state_dict(torch.load(filename + ".target"))
+            self.qnetwork_target.load_state_dict(torch.load(filename + ".target", weights_only=True))
 
     def step(self, state, action, reward, next_state, done, train=True):
         self.memory.add(state, action, reward, next_state, done)

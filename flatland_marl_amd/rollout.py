@@ -38,6 +38,10 @@ class RolloutBatch:
         # episode of at most S steps a smaller max_alt_depth >= max(S, depth + 1) gives the same rollout.
         self.max_alt_depth = int(max_alt_depth)
         self.Lp = self.max_alt_depth + 40
+        if self.Lp < b.T1 + 1:
+            # reset() copies the shortest paths (up to depth + 2 elements) into rows of Lp elements
+            raise ValueError("max_alt_depth + 40 = %d path elements cannot hold a shortest path of depth + 2 = %d"
+                             % (self.Lp, b.T1 + 1))
         self.speed = torch.as_tensor(np.asarray(speed, np.float64).reshape(E, A), device=dev)
         self.init_dir = b.direction.clone() if initial_direction is None else \
             torch.as_tensor(np.asarray(initial_direction, np.int32).reshape(E, A), device=dev)
@@ -245,6 +249,14 @@ class RolloutBatch:
         self.t += 1
         info["net_in"], info["best"] = net_in, best
         return info
+
+    def flagged_agents(self):
+        """(agents whose path or alternatives raised in the reference's terms, agents that hit a capacity of this
+        batch: more than cap_alt alternatives or a path longer than Lp) since the last reset.  A flagged agent is
+        treated as having no alternatives and stops in front of its switch; the second kind has no counterpart
+        in the reference and means cap_alt / max_alt_depth are too small for the maps."""
+        err = self.agent_err
+        return int((err != 0).sum().item()), int((err == 5).sum().item())
 
     # ------------------------------------------------------------------ host views (tests)
     def maps_numpy(self, e=0, R=None):

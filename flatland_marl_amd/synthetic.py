@@ -1,9 +1,9 @@
 """Synthetic batches of environments built from stored rail grids.
 
-No rail generator ships with this package: batches are made from a few real
-grids (uint16 transition maps) by applying the eight symmetries of the square to
-the grid and by re-drawing which (start, heading) and which target each agent
-gets from the grid's own station cells, with numpy.random.default_rng(seed + env).
+Batches are made from a few real grids (uint16 transition maps) by applying the
+eight symmetries of the square to the grid and by re-drawing which (start,
+heading) and which target each agent gets from the grid's own station cells, with
+numpy.random.default_rng(seed + env).  (railgen.py draws whole grids instead.)
 """
 import numpy as np
 
@@ -48,10 +48,12 @@ def transform(grid, pos_rc, heading, sym):
     return np.ascontiguousarray(grid), pos, heading
 
 
-def make_batch(fixtures, E, A, seed=0, square_only=True):
+def make_batch(fixtures, E, A, seed=0, square_only=True, first=0):
     """E environments with A agents each, cycling over fixtures x symmetries.
 
     fixtures: list of dicts with grid, initial_position, direction, target, speed (tests/golden/envs/*.npz).
+    first: global index of the batch's first environment; environment first + e of a larger job is the same
+    whichever process builds it (a rank's shard equals the slice of the single-process batch).
     Returns dict(grid [E,H,W] uint16, start [E,A,2], direction [E,A], target [E,A,2], speed [E,A]).
     """
     variants = []
@@ -70,8 +72,8 @@ def make_batch(fixtures, E, A, seed=0, square_only=True):
     target = np.empty((E, A, 2), np.int32)
     speed = np.empty((E, A), np.float64)
     for e in range(E):
-        g, st, hd, tg = variants[e % len(variants)]
-        rng = np.random.default_rng(seed + e)
+        g, st, hd, tg = variants[(first + e) % len(variants)]
+        rng = np.random.default_rng(seed + first + e)
         grid[e] = g
         pick = rng.choice(len(st), size=A, replace=len(st) < A)
         start[e] = st[pick]

@@ -139,7 +139,8 @@ class DeviceReplay:
 
 class BatchedTrainer:
     def __init__(self, rollout: RolloutBatch, agent, replay_capacity=None, max_steps=200, start_eps=1.0, end_eps=0.005,
-                 eps_decay=0.998, crash_penalty=False, switch2switch=False, max_learns_per_step=None, seed=0):
+                 eps_decay=0.998, crash_penalty=False, switch2switch=False, max_learns_per_step=None, seed=0,
+                 strict=False):
         self.ro = rollout
         self.agent = agent
         b = rollout.b
@@ -166,6 +167,7 @@ class BatchedTrainer:
             self.has_buf = torch.zeros((n,), dtype=torch.bool, device=dev)
             self.buf_rew = torch.zeros((n,), dtype=torch.float64, device=dev)
         self.max_learns_per_step = max_learns_per_step
+        self.strict = strict
         self.t_step = 0
         self.n_learn = 0
         self.n_transitions = 0
@@ -265,6 +267,14 @@ class BatchedTrainer:
                 break
         self.eps = max(self.end_eps, self.eps_decay * self.eps)
         done_frac = ro.done.float().mean().item()
+        flagged, overflowed = ro.flagged_agents()
+        if overflowed:
+            # not a case of the reference: this batch's own capacities were too small, the agents concerned stood still
+            raise OverflowError("%d agents had more than cap_alt=%d alternatives or a path longer than %d elements"
+                                % (overflowed, ro.cap_alt, ro.Lp))
+        if flagged and self.strict:
+            raise RuntimeError("%d agents' paths or alternatives raised (IndexError / KeyError / AssertionError in "
+                               "the reference's terms)" % flagged)
         return dict(steps=steps, env_steps=steps * ro.E, done_agents=done_frac,
                     mean_reward=float(total_reward.mean().item()), eps=self.eps, learns=self.n_learn,
-                    transitions=self.n_transitions)
+                    transitions=self.n_transitions, agents_flagged=flagged)

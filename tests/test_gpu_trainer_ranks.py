@@ -50,7 +50,8 @@ def _worker(rank, world, port, out_dir):
     w = agent.qnetwork_local.flat_params()
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), w=w.cpu().numpy(), changed=float((w - w0).abs().max().item()),
              learns=out["learns"], transitions=out["transitions"], steps=out["steps"],
-             target=agent.qnetwork_target.flat_params().cpu().numpy())
+             target=agent.qnetwork_target.flat_params().cpu().numpy(), start=data["start"], goal=data["target"],
+             final_pos=ro.pos.cpu().numpy(), flagged=out["agents_flagged"])
     dist.destroy_process_group()
 
 
@@ -61,7 +62,10 @@ def test_two_ranks_keep_identical_weights(tmp_path):
     r = [dict(np.load(os.path.join(tmp_path, "r%d.npz" % i))) for i in range(world)]
     assert int(r[0]["learns"]) == int(r[1]["learns"]) > 0          # ranks agree on the number of learn steps
     assert int(r[0]["steps"]) == int(r[1]["steps"])                 # and on when the episode ends
-    assert int(r[0]["transitions"]) != int(r[1]["transitions"]) or True
+    # the ranks really stepped different environments: other agents, other targets, other final positions
+    assert not np.array_equal(r[0]["start"], r[1]["start"]) and not np.array_equal(r[0]["goal"], r[1]["goal"])
+    assert not np.array_equal(r[0]["final_pos"], r[1]["final_pos"])
+    assert int(r[0]["transitions"]) > 0 and int(r[1]["transitions"]) > 0
     assert float(r[0]["changed"]) > 0
     assert np.array_equal(r[0]["w"], r[1]["w"])                     # same averaged gradient, same Adam state
     assert np.array_equal(r[0]["target"], r[1]["target"])

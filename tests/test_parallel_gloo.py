@@ -25,14 +25,15 @@ def _worker(rank, world, port, n_total, out_dir):
     lo, hi = parallel.shard_range(n_total, r, w)
     # every rank builds only its own environments; seeds are global environment indices
     fx = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "envs", "Test_0_Level_0.npz")))
-    mine = make_batch([fx], hi - lo, 5, seed=lo, square_only=True)
+    mine = make_batch([fx], hi - lo, 5, seed=11, square_only=True, first=lo)
     t = parallel.max_over_ranks(1.0 + rank)
     total = parallel.sum_over_ranks(hi - lo)
     fewest = parallel.min_over_ranks(3 + 2 * rank)
     g = torch.full((1000,), float(rank + 1))
     parallel.allreduce_mean_(g)
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), lo=lo, hi=hi, t=t, total=total, fewest=fewest, g=g.numpy(),
-             start=mine["start"], target=mine["target"])
+             start=mine["start"], target=mine["target"], grid=mine["grid"], speed=mine["speed"],
+             direction=mine["direction"])
     dist.destroy_process_group()
 
 
@@ -49,13 +50,12 @@ def test_two_ranks_shard_and_reduce(tmp_path):
     # shards are what a single process would have built for the same global environment indices
     from flatland_marl_amd.synthetic import make_batch
     fx = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "envs", "Test_0_Level_0.npz")))
+    whole = make_batch([fx], n_total, 5, seed=11)
     for i in range(world):
         lo, hi = int(r[i]["lo"]), int(r[i]["hi"])
-        for e in range(lo, hi):
-            one = make_batch([fx], 1, 5, seed=e)
-            # environment e cycles through the symmetry variants by its local index, so compare agents only
-            assert one["start"].shape == (1, 5, 2)
-    assert r[0]["start"].shape[0] + r[1]["start"].shape[0] == n_total
+        for key in ("grid", "start", "direction", "target", "speed"):
+            assert np.array_equal(r[i][key], whole[key][lo:hi]), (i, key)
+    assert not np.array_equal(r[0]["start"][0], r[1]["start"][0])     # the ranks hold different environments
 
 
 def test_shard_range_tiles():
