@@ -29,6 +29,7 @@ _SIGNATURES = {
     "flm_distance_chains": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     "flm_shortest_paths": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     "flm_bitmaps": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p],
+    "flm_bitmaps_static": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     "flm_observations": [_p, _p, _i, _i, _i, _p, _p],
     "flm_columns": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     "flm_observations_columns": [_p, _i, _i, _i, _i, _i, _p, _p],

@@ -868,4 +868,40 @@ extern "C" int flm_reorder_rails(const uint8_t* obs_in, uint8_t* obs_out, int n,
   return FLM_OK;
 }
 
+// ---- flm_bitmaps without a caller-provided workspace and without any allocation -------------------------
+// The column-form workspace of flm_bitmaps lives in a file-scope device array.  In host code the array's name
+// is only a handle: its device address is looked up once per device (with that device current) and kept.
+// FLM_BITMAPS_STATIC_MAX_COLS int16 entries (n_paths * T1 of one call): 4 MiB
+static __device__ __align__(256) int16_t scratch[FLM_BITMAPS_STATIC_MAX_COLS];
+
+#include <mutex>
+static std::mutex scratch_lock;
+static int16_t* scratch_ptr[64];        // per device ordinal; nullptr = not looked up yet
+
+// Device address of this device's copy of `scratch` (each GPU holds its own copy at its own address).
+static int16_t* scratch_for_current_device() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> guard(scratch_lock);
+  if (!scratch_ptr[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return nullptr;
+    scratch_ptr[dev] = static_cast<int16_t*>(p);
+  }
+  return scratch_ptr[dev];
+}
+
+extern "C" int flm_bitmaps_static(const int32_t* path_cell, const int32_t* path_len, const int32_t* agent_flat,
+                                  const int32_t* pos_cell, const int32_t* target_cell, const int32_t* tpc,
+                                  const int32_t* node_id, const int32_t* cell_rail, const int32_t* edge_info, int E, int A,
+                                  int n_paths, int H, int W, int capR, int Rp, int T1, int plane_stride, int Lcap,
+                                  int shift, int8_t* planes, int32_t* err, void* stream) {
+  if (n_paths <= 0 || T1 <= 1) return FLM_E_ARG;
+  if ((long long)n_paths * T1 > (long long)FLM_BITMAPS_STATIC_MAX_COLS) return FLM_E_CAPACITY;
+  int16_t* ws = scratch_for_current_device();
+  if (!ws) return FLM_E_LAUNCH;
+  return flm_bitmaps(path_cell, path_len, agent_flat, pos_cell, target_cell, tpc, node_id, cell_rail, edge_info, E, A,
+                     n_paths, H, W, capR, Rp, T1, plane_stride, Lcap, shift, ws, planes, err, stream);
+}
+
 extern "C" int flm_abi_version(void) { return 1; }

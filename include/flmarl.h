@@ -34,6 +34,7 @@ extern "C" {
 #define FLM_OK 0
 #define FLM_E_ARG (-1)      /* bad size, null pointer, unsupported capacity */
 #define FLM_E_LAUNCH (-2)   /* the HIP runtime refused a launch or a memset */
+#define FLM_E_CAPACITY (-3) /* the call needs more than a fixed-size internal buffer holds */
 
 #define FLM_AGENT_OK 0
 #define FLM_AGENT_INDEX_ERROR 2   /* src/rail_observations.py:350, :367 */
@@ -147,6 +148,19 @@ int flm_bitmaps(const int32_t* path_cell, const int32_t* path_len, const int32_t
                 const int32_t* node_id, const int32_t* cell_rail, const int32_t* edge_info, int E, int A,
                 int n_paths, int H, int W, int capR, int Rp, int T1, int plane_stride, int Lcap, int shift,
                 int16_t* cols_ws, int8_t* planes, int32_t* err, void* stream);
+
+/* flm_bitmaps for callers that cannot allocate device memory (code under HIP graph capture, serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results as flm_bitmaps
+ * without cols_ws: the column-form workspace is a fixed 4 MiB array inside the library (one copy per GPU, held
+ * until the process ends), so n_paths * T1 <= FLM_BITMAPS_STATIC_MAX_COLS (2,097,152); larger calls return
+ * FLM_E_CAPACITY and launch nothing.  The call allocates and frees nothing.  Every call on a GPU uses that GPU's one
+ * array: calls that overlap on the same GPU (different streams or host threads) race; calls on one stream do not. */
+#define FLM_BITMAPS_STATIC_MAX_COLS (2 * 1024 * 1024)
+int flm_bitmaps_static(const int32_t* path_cell, const int32_t* path_len, const int32_t* agent_flat,
+                       const int32_t* pos_cell, const int32_t* target_cell, const int32_t* tpc,
+                       const int32_t* node_id, const int32_t* cell_rail, const int32_t* edge_info, int E, int A,
+                       int n_paths, int H, int W, int capR, int Rp, int T1, int plane_stride, int Lcap, int shift,
+                       int8_t* planes, int32_t* err, void* stream);
 
 /* Observation of every agent: its own plane and the two heat planes "sum over the other agents" of the
  * positive and of the negative entries.
