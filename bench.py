@@ -219,6 +219,10 @@ def main():
     ap.add_argument("--obs-serial", type=int, default=1,
                     help="1: observation kernels run one after the other on the main stream after the other stages; "
                          "2: pipelined, the other stages of the next sub-batch run on a side stream meanwhile")
+    ap.add_argument("--paths", default="fused", choices=["fused", "dense"],
+                    help="fused: paths and columns straight from the chain index (default when the tables fit the LDS); "
+                         "dense: distance maps -> shortest paths -> columns as separate kernels")
+    ap.add_argument("--no-store-paths", action="store_true", help="fused only: do not write the path elements to HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rollout", action="store_true", help="skip the env-steps/s sample of the batched rollout")
     ap.add_argument("--rollout-workload", default="cfg2g", choices=["cfg2", "cfg2g"])
@@ -278,6 +282,20 @@ def main():
     ready = [torch.cuda.Event() for _ in batches]
     consumed = [None for _ in batches]
 
+    fused = args.paths == "fused" and all(b.fused_fits() for b in batches)
+
+    def front(b):
+        """Everything before the observation sweep: switch graph, state numbering, chain index, then either the
+        fused kernel (anchor distances + walks + columns in LDS) or dense distance maps -> walks -> columns."""
+        b.build_graph(sync=False)
+        if fused:
+            b.chain_index()
+            b.paths_columns_fused(shift=1, store_paths=not args.no_store_paths)
+        else:
+            b.compute_distances()
+            b.shortest_paths()
+            b.columns(shift=1)
+
     def step_pipelined(ev=None):
         # side stream: graph .. columns of sub-batch i+1 while the main stream writes the observations of sub-batch i
         side = streams[0]
@@ -286,10 +304,7 @@ def main():
             with torch.cuda.stream(side):
                 if consumed[ci] is not None:
                     side.wait_event(consumed[ci])       # the previous step's observation kernel has read the columns
-                b.build_graph(sync=False)
-                b.compute_distances()
-                b.shortest_paths()
-                b.columns(shift=1)
+                front(b)
                 ready[ci].record(side)
             main_stream.wait_event(ready[ci])
             b.stream = main_stream
@@ -309,10 +324,7 @@ def main():
             st.wait_stream(main_stream)
         for ci, b in enumerate(batches):
             with torch.cuda.stream(b.stream):
-                b.build_graph(sync=False)
-                b.compute_distances()
-                b.shortest_paths()
-                b.columns(shift=1)
+                front(b)
                 if not args.obs_serial:
                     if ev is not None:
                         ev[ci][0].record(b.stream)
@@ -390,7 +402,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, desc), "envs_per_gpu": E, "agents": A,
                        "rails_padded": int(Rp), "depth": depth, "agents_flagged": n_err, "sub_batches": n_chunks, "streams": len(streams),
-                       "step": "graph build + distance maps + shortest paths + occupancy columns + observations (dense planes are plane 0 of each observation)"},
+                       "paths": ("fused" if fused else "dense") + ("" if not (fused and args.no_store_paths) else ", path elements not stored"),
+                       "step": "graph build + chain index + anchor distances + shortest paths + occupancy columns + observations (dense planes are plane 0 of each observation)"},
             "roofline": {"kernel": "observations_columns_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "achieved_physical": physical, "frac_physical": None if physical is None else physical / 8000.0,

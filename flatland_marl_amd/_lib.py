@@ -13,7 +13,7 @@ FLM_OK = 0
 AGENT_ERRORS = {2: IndexError, 3: KeyError, 4: AssertionError, 5: OverflowError}
 GRAPH_ERR_NODES, GRAPH_ERR_RAILS, GRAPH_ERR_CELLS, GRAPH_ERR_STATES = 1, 2, 4, 8
 MAX_NODES = 2048
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _p = C.c_void_p
 _i = C.c_int
@@ -22,10 +22,13 @@ _u32 = C.c_uint32
 _SIGNATURES = {
     "flm_abi_version": [],
     "flm_graph_build": [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
-    "flm_state_index": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p],
+    "flm_state_index": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     "flm_distance_bfs": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p],
     "flm_target_slots": [_p, _i, _i, _p, _p, _p, _p],
-    "flm_chain_index": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
+    "flm_chain_index": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "flm_paths_columns_lds_bytes": [_i, _i, _i, _i, _i, _i, _i],
+    "flm_paths_columns_workspace": [_i, _i, _i, _i],
+    "flm_paths_columns": [_p] * 22 + [_i] * 14 + [_p] * 8,
     "flm_distance_chains": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     "flm_shortest_paths": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     "flm_bitmaps": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p],
@@ -60,7 +63,7 @@ _SIGNATURES = {
                                  C.c_double, _p],
 }
 
-_LONG_RESULT = {"flm_dqn_param_count", "flm_dqn_forward_workspace", "flm_dqn_learn_workspace",
+_LONG_RESULT = {"flm_paths_columns_lds_bytes", "flm_paths_columns_workspace", "flm_dqn_param_count", "flm_dqn_forward_workspace", "flm_dqn_learn_workspace",
                 "flm_dqn_learn_workspace_u8"}
 _lib = None
 

@@ -87,6 +87,7 @@ class ObservationBatch:
         self.counts = torch.zeros((E, 4), **i32)
         self.cell_idx = torch.empty((E, HW), **i32)
         self.n_cells = torch.empty((E,), **i32)
+        self.idx_cell = torch.empty((E, self.cap_cells), **i32)
         self.pred = None     # reverse-move table: only the breadth-first fallback needs it
 
     def _launch_graph(self):
@@ -96,7 +97,7 @@ class ObservationBatch:
              ptr(self.node_cell), ptr(self.edge_info), ptr(self.edge_cell_off), ptr(self.edge_cells),
              ptr(self.cell_rail), ptr(self.counts), s)
         call("flm_state_index", ptr(self.grid), E, H, W, self.cap_cells, ptr(self.cell_idx), ptr(self.n_cells),
-             None, ptr(self.counts), s)
+             None, ptr(self.counts), ptr(self.idx_cell), s)
 
     def build_graph(self, sync=True):
         """Switch graph + cell->rail table + state numbering for the BFS.
@@ -158,10 +159,11 @@ class ObservationBatch:
         i32 = dict(dtype=torch.int32, device=dev)
         s = self.stream.cuda_stream
         capS = self.cap_cells * 4
-        if getattr(self, "dist", None) is None:
+        if getattr(self, "tslot", None) is None:
             self.tslot = torch.empty((E, A), **i32)
             self.n_slots = torch.empty((E,), **i32)
             self.slot_target = torch.empty((E, A), **i32)
+        if getattr(self, "dist", None) is None:
             self.dist = torch.empty((E, A, capS), dtype=torch.int16, device=dev)
         if method is None:
             method = "chains" if capS * 10 + capS // 8 + 512 <= 159 * 1024 else "bfs"
@@ -170,38 +172,100 @@ class ObservationBatch:
             if self.pred is None:
                 self.pred = torch.empty((E, capS, 4), dtype=torch.int16, device=dev)
             call("flm_state_index", ptr(self.grid), E, self.H, self.W, self.cap_cells, ptr(self.cell_idx),
-                 ptr(self.n_cells), ptr(self.pred), ptr(self.counts), s)
+                 ptr(self.n_cells), ptr(self.pred), ptr(self.counts), ptr(self.idx_cell), s)
             call("flm_distance_bfs", ptr(self.pred), ptr(self.cell_idx), ptr(self.n_cells), ptr(self.target_cell), E,
                  A, self.H, self.W, self.cap_cells, ptr(self.tslot), ptr(self.n_slots), ptr(self.slot_target),
                  ptr(self.dist), s)
             return self
+        self.chain_index()
+        if self.lds_anchor * 80 > 159 * 1024:                # the anchors' labels of 32 targets do not fit the LDS
+            return self.compute_distances(method="bfs")
+        call("flm_distance_chains", ptr(self.chain_root), ptr(self.chain_steps), ptr(self.chain_edges),
+             ptr(self.n_anchor), ptr(self.n_cells), ptr(self.cell_idx), ptr(self.slot_target), ptr(self.n_slots), E, A,
+             self.H, self.W, self.cap_cells, self.cap_anchor, self.lds_anchor, ptr(self.dist), ptr(self.counts), s)
+        return self
+
+    def chain_index(self):
+        """Distinct targets per environment and the chain index of every grid (anchors, forced-move chains, the
+        walk tables): what both the dense distance maps and the fused path kernel start from."""
+        E, A, dev = self.E, self.A, self.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        s = self.stream.cuda_stream
+        capS = self.cap_cells * 4
+        if getattr(self, "tslot", None) is None:
+            self.tslot = torch.empty((E, A), **i32)
+            self.n_slots = torch.empty((E,), **i32)
+            self.slot_target = torch.empty((E, A), **i32)
         if getattr(self, "chain_root", None) is None:
-            # anchors: states with a choice (at most two per switch cell and heading pair) + target-cell states
-            self.cap_anchor = int(min(0xFFF0, 4 * self.capN + 4 * A + 16))
+            # anchors: states with a choice (at most two per switch cell and heading pair), target-cell states,
+            # and the few states with one move that a walk does not treat as forced (dead ends)
+            self.cap_anchor = int(min(0x7FF0, 4 * self.capN + 4 * A + 256))
             self.chain_root = torch.empty((E, capS), dtype=torch.int16, device=dev)
             self.chain_steps = torch.empty((E, capS), dtype=torch.int16, device=dev)
             self.chain_edges = torch.empty((E, self.cap_anchor, 4), **i32)
             self.n_anchor = torch.empty((E,), **i32)
             self.chain_succ = torch.empty((E, capS), dtype=torch.int16, device=dev)
             self.chain_choice = torch.empty((E, capS, 4), dtype=torch.int16, device=dev)
+            self.chain_walk = self.move_edge = self.move_succ = None
+            if capS <= 32768:
+                self.chain_walk = torch.empty((E, capS), dtype=torch.int16, device=dev)
+                self.move_edge = torch.empty((E, self.cap_anchor, 4), **i32)
+                self.move_succ = torch.empty((E, self.cap_anchor, 4), dtype=torch.int16, device=dev)
         call("flm_target_slots", ptr(self.target_cell), E, A, ptr(self.tslot), ptr(self.n_slots), ptr(self.slot_target), s)
         call("flm_chain_index", ptr(self.grid), ptr(self.cell_idx), ptr(self.n_cells), ptr(self.target_cell), E, A,
              self.H, self.W, self.cap_cells, self.cap_anchor, ptr(self.chain_root), ptr(self.chain_steps),
-             ptr(self.chain_edges), ptr(self.n_anchor), ptr(self.counts), ptr(self.chain_succ), ptr(self.chain_choice), s)
+             ptr(self.chain_edges), ptr(self.n_anchor), ptr(self.counts), ptr(self.chain_succ), ptr(self.chain_choice),
+             ptr(self.chain_walk), ptr(self.move_edge), ptr(self.move_succ), s)
         self._succ_valid = True
         if getattr(self, "lds_anchor", None) is None:
             # anchors = states with a choice of moves (fixed by the grid) + states on target cells (<= 4*A).
             # The LDS tables are sized for the count seen now plus a margin for later target assignments;
             # an environment that outgrows it is flagged in counts (check_graph) and this size is recomputed.
             n_now = int(self.n_anchor.max().item())
-            fit = (159 * 1024 - 16 * 2 * 256 * 2 - 128) // 100
-            self.lds_anchor = int(min(self.cap_anchor, n_now + min(4 * A, 64), max(fit, 1), 2047))
-            if self.lds_anchor < n_now:
-                return self.compute_distances(method="bfs")
-        call("flm_distance_chains", ptr(self.chain_root), ptr(self.chain_steps), ptr(self.chain_edges),
-             ptr(self.n_anchor), ptr(self.n_cells), ptr(self.cell_idx), ptr(self.slot_target), ptr(self.n_slots), E, A,
-             self.H, self.W, self.cap_cells, self.cap_anchor, self.lds_anchor, ptr(self.dist), ptr(self.counts), s)
+            self.lds_anchor = int(min(self.cap_anchor, n_now + min(4 * A, 64)))
+            # distinct targets per environment, rounded up to the eight targets one decision word holds
+            self.lds_slots = (int(self.n_slots.max().item()) + 7) // 8 * 8
         return self
+
+    def fused_fits(self, max_depth=None):
+        """Can paths_columns_fused run for this batch (tables within the LDS and the kernel's index widths)?"""
+        from ._lib import query
+        if getattr(self, "chain_walk", None) is None or self.H > 256 or self.W > 256 or self.T1 > 512:
+            return False
+        Lcap = (self.T1 if max_depth is None else int(max_depth)) + 1
+        need = query("flm_paths_columns_lds_bytes", self.A, self.cap_cells, self.lds_anchor, self.lds_slots, self.capR, Lcap,
+                     self.T1)
+        return 0 < need <= 160 * 1024 - 512
+
+    def paths_columns_fused(self, shift=1, store_paths=True, max_depth=None):
+        """shortest_paths() + columns() in one launch straight from the chain index (no dense distance maps)."""
+        E, A, dev = self.E, self.A, self.device
+        max_depth = self.T1 if max_depth is None else int(max_depth)
+        Lcap = max_depth + 1
+        if store_paths and getattr(self, "Lcap", None) != Lcap:
+            self.path_cell = torch.empty((E, A, Lcap), dtype=torch.int32, device=dev)
+            self.path_meta = torch.empty((E, A, Lcap), dtype=torch.int32, device=dev)
+            self.Lcap = Lcap
+        if getattr(self, "path_len", None) is None:
+            self.path_len = torch.empty((E, A), dtype=torch.int32, device=dev)
+        if getattr(self, "cols", None) is None:
+            self.cols = torch.empty((E, A, self.T1), dtype=torch.int16, device=dev)
+        if getattr(self, "agent_err", None) is None:
+            self.agent_err = torch.empty((E, A), dtype=torch.int32, device=dev)
+        from ._lib import query
+        n_ws = query("flm_paths_columns_workspace", E, A, self.lds_anchor, self.lds_slots)
+        if getattr(self, "_fused_ws", None) is None or self._fused_ws.numel() < n_ws:
+            self._fused_ws = torch.empty((n_ws,), dtype=torch.int32, device=dev)
+        call("flm_paths_columns", ptr(self.chain_walk), ptr(self.chain_root), ptr(self.chain_steps), ptr(self.chain_edges),
+             ptr(self.move_edge),
+             ptr(self.move_succ), ptr(self.n_anchor), ptr(self.n_cells), ptr(self.cell_idx), ptr(self.idx_cell), ptr(self.cell_rail),
+             ptr(self.node_id), ptr(self.edge_info), ptr(self.tslot), ptr(self.n_slots), ptr(self.slot_target),
+             ptr(self.pos_cell), ptr(self.direction), ptr(self.pos_cell), ptr(self.target_cell), ptr(self.status),
+             ptr(self.tpc), E, A, self.H, self.W, self.cap_cells, self.cap_anchor, self.lds_anchor, self.lds_slots,
+             self.capR, self.Rp, self.T1, max_depth, Lcap, int(shift), ptr(self._fused_ws),
+             ptr(self.path_cell) if store_paths else None, ptr(self.path_meta) if store_paths else None,
+             ptr(self.path_len), ptr(self.cols), ptr(self.agent_err), ptr(self.counts), self.stream.cuda_stream)
+        return self.cols
 
     def succ_table(self):
         """Forced-move table of the chain index (None after a breadth-first distance computation)."""
@@ -277,9 +341,20 @@ class ObservationBatch:
         self.obs = out
         return out
 
-    def reset_fused(self, sync=True):
-        """reset() + observations() without the dense intermediate planes."""
+    def reset_fused(self, sync=True, fused_paths=None, store_paths=True):
+        """reset() + observations() without the dense intermediate planes.  fused_paths (default: whenever the
+        tables fit the LDS) computes paths and columns straight from the chain index, without the dense distance
+        maps; False takes distance maps -> shortest paths -> columns."""
         self.build_graph(sync=sync)
+        capS = self.cap_cells * 4
+        chains = capS * 10 + capS // 8 + 512 <= 159 * 1024
+        if fused_paths is not False and chains:
+            self.chain_index()
+            if self.fused_fits():
+                self.paths_columns_fused(shift=1, store_paths=store_paths)
+                return self.observations_fused()
+            if fused_paths:
+                raise _lib.FlmError("the fused path kernel's tables do not fit the LDS for this batch")
         self.compute_distances()
         self.shortest_paths()
         self.columns(shift=1)

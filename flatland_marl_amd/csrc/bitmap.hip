@@ -1,5 +1,6 @@
 // Path -> rail-occupancy plane, and the per-agent observation (own plane + two heat planes).
 #include "flm_common.h"
+#include "flm_columns.h"
 
 
 namespace flm {
@@ -155,23 +156,7 @@ __global__ __launch_bounds__(256) void bitmaps_kernel(
   }
 }
 
-// ---- column form, one wavefront per path ---------------------------------------------------------------
-// The same plane as bitmaps_kernel, produced without a sequential pass.  Lane l owns the time steps
-// l, l+64, ...  The two order-dependent quantities of the sequential definition become bit scans over
-// wave ballots (one 64-bit mask per 64 steps):
-//   * the node through which the current rail was entered = the last earlier step that left a switch
-//     cell (highest set bit below the step in the "leaves a switch" masks), or the initial entry;
-//   * a step on a switch cell shows the rail and sign of the next step that is on a rail
-//     (lowest set bit above the step in the "on a rail" masks).
-// The first error in time order is the one reported, as in the sequential definition.
-#define FLM_COL_KT 8   // up to 512 time steps
-
-__device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-  return v;
-}
-
+// ---- column form, one wavefront per path (the scans are in flm_columns.h) ---------------------------------
 __global__ __launch_bounds__(256) void columns_wave_kernel(
     const int32_t* __restrict__ path_cell, const int32_t* __restrict__ path_len, const int32_t* __restrict__ agent_flat,
     const int32_t* __restrict__ pos_cell, const int32_t* __restrict__ target_cell, const int32_t* __restrict__ tpc_all,
@@ -201,15 +186,19 @@ __global__ __launch_bounds__(256) void columns_wave_kernel(
   const int KT = (T1 + 63) >> 6;
 
   // the agent stops advancing at the first path element on the target cell
-  int kmin = len > 0 ? len - 1 : 0;
-  for (int k = lane; k < len; k += 64) {
-    const int c = (k == 0) ? pos : pcell[k];
-    if (c == tgt) kmin = min(kmin, k);
+  int kstop = len > 0 ? len - 1 : 0;
+  for (int base = 0; base < len; base += 64) {
+    const int k = base + lane;
+    const int fl = first_lane(k < len && ((k == 0) ? pos : pcell[k]) == tgt);
+    if (fl < 64) {
+      kstop = base + fl;
+      break;
+    }
   }
-  const int kstop = wave_min(kmin);
-  int nmin = T1;
+  int n = T1;                     // steps kept: cut after the first visit of the target
   for (int q = 0; q < KT; q++) {
     const int ts = lane + 64 * q;
+    bool at_target = false;
     if (ts < T1) {
       int k = ts / tpc;
       if (k > kstop) k = kstop;
@@ -218,130 +207,16 @@ __global__ __launch_bounds__(256) void columns_wave_kernel(
       s_cell[ts] = c;
       s_rail[ts] = inside ? cell_rail[c] : -1;
       s_node[ts] = inside ? node_id[c] : -1;
-      if (c == tgt) nmin = min(nmin, ts + 1);
+      at_target = c == tgt;
     }
+    const int fl = first_lane(at_target);
+    if (fl < 64 && n == T1) n = 64 * q + fl + 1;
   }
-  const int n = wave_min(nmin);   // steps kept: cut after the first visit of the target
   __builtin_amdgcn_wave_barrier();
 
-  // masks over the kept steps
-  unsigned long long m_rail[FLM_COL_KT], m_ev[FLM_COL_KT];
-  int key_err_ts = 0x7FFFFFFF;   // first step at which leaving a cell that is neither rail nor node fails
-#pragma unroll
-  for (int q = 0; q < FLM_COL_KT; q++) {
-    m_rail[q] = 0;
-    m_ev[q] = 0;
-    if (q < KT) {
-      const int ts = lane + 64 * q;
-      bool on_rail = false, ev = false;
-      if (ts < n) {
-        on_rail = s_rail[ts] != -1;
-        ev = !on_rail && ts + 1 < n && s_cell[ts] != s_cell[ts + 1];
-        if (ev && s_node[ts] < 0) key_err_ts = min(key_err_ts, ts);
-      }
-      m_rail[q] = __ballot(on_rail);
-      m_ev[q] = __ballot(ev);
-    }
-  }
-  // initial entry (wave-uniform)
-  int err = 0, en0 = -1, ecp0 = -1;
-  if (s_rail[0] != -1) {
-    int i = -1;   // first kept step >= 1 that is not on a rail
-#pragma unroll
-    for (int q = FLM_COL_KT - 1; q >= 0; q--)
-      if (q < KT) {
-        unsigned long long valid = (n - 64 * q >= 64) ? ~0ull : ((n - 64 * q) > 0 ? ((1ull << (n - 64 * q)) - 1) : 0ull);
-        unsigned long long holes = ~m_rail[q] & valid;
-        if (q == 0) holes &= ~1ull;
-        if (holes) i = 64 * q + __ffsll((long long)holes) - 1;
-      }
-    if (i < 0) err = FLM_AGENT_INDEX_ERROR;
-    else {
-      const int nid = s_node[i];
-      if (nid < 0) err = FLM_AGENT_KEY_ERROR;
-      else {
-        const int c0 = s_cell[i - 1], c1 = s_cell[i];
-        const int cp = (direction_to_point(c0 / W, c0 % W, c1 / W, c1 % W) + 2) & 3;
-        const int32_t* ei = edge_info + s_rail[0] * 5;
-        if (nid == ei[2] && cp == ei[3]) { en0 = ei[0]; ecp0 = ei[1]; }
-        else if (nid == ei[0] && cp == ei[1]) { en0 = ei[2]; ecp0 = ei[3]; }
-      }
-    }
-  } else {
-    const int nid = s_node[0];
-    if (nid < 0) err = FLM_AGENT_KEY_ERROR;
-    else if (n < 2) err = FLM_AGENT_INDEX_ERROR;
-    else {
-      const int c0 = s_cell[0], c1 = s_cell[1];
-      en0 = nid;
-      ecp0 = direction_to_point(c0 / W, c0 % W, c1 / W, c1 % W);
-    }
-  }
-  // sign of every step on a rail
-  int assert_err_ts = 0x7FFFFFFF;
-#pragma unroll
-  for (int q = 0; q < FLM_COL_KT; q++)
-    if (q < KT) {
-      const int ts = lane + 64 * q;
-      if (ts < n && ((m_rail[q] >> lane) & 1)) {
-        // last earlier step that left a switch cell
-        int le = -1;
-        unsigned long long below = m_ev[q] & lanemask_lt();
-        if (below) le = 64 * q + 63 - __clzll((long long)below);
-        else {
-#pragma unroll
-          for (int p = FLM_COL_KT - 1; p >= 0; p--)
-            if (p < q && le < 0 && m_ev[p]) le = 64 * p + 63 - __clzll((long long)m_ev[p]);
-        }
-        int en = en0, ecp = ecp0;
-        if (le >= 0) {
-          const int c0 = s_cell[le], c1 = s_cell[le + 1];
-          en = s_node[le];
-          ecp = direction_to_point(c0 / W, c0 % W, c1 / W, c1 % W);
-        }
-        const int32_t* ei = edge_info + s_rail[ts] * 5;
-        int dir = 0;
-        if (en == ei[2] && ecp == ei[3]) dir = 1;
-        else if (en == ei[0] && ecp == ei[1]) dir = -1;
-        if (dir == 0) assert_err_ts = min(assert_err_ts, ts);
-        s_dir[ts] = dir;
-      }
-    }
-  if (!err) {
-    const int k_ts = wave_min(key_err_ts), a_ts = wave_min(assert_err_ts);
-    if (k_ts != 0x7FFFFFFF || a_ts != 0x7FFFFFFF) err = (k_ts < a_ts) ? FLM_AGENT_KEY_ERROR : FLM_AGENT_ASSERT_ERROR;
-  }
+  const int err = columns_from_steps<int, int>(s_cell, s_rail, s_node, s_dir, n, T1, CellLinear{W}, RailEndsGlobal{edge_info}, Rp,
+                                               shift, lane, cols + (size_t)gp * T1);
   if (lane == 0) err_out[gp] = err;
-  __builtin_amdgcn_wave_barrier();
-  // output: a step on a rail shows itself, a step on a switch cell the next step that is on a rail
-  int16_t* col = cols + (size_t)gp * T1;
-  for (int t = lane; t < T1; t += 64) {
-    const int ts = t - shift;
-    int v = -1;
-    if (!err && ts >= 0 && ts < n) {
-      const int q = ts >> 6, b = ts & 63;
-      int src = -1;
-      unsigned long long mq = 0;
-#pragma unroll
-      for (int p = 0; p < FLM_COL_KT; p++)
-        if (p == q) mq = m_rail[p];
-      if ((mq >> b) & 1) src = ts;
-      else {
-        unsigned long long above = (b == 63) ? 0ull : (mq & (~0ull << (b + 1)));
-        if (above) src = 64 * q + __ffsll((long long)above) - 1;
-        else {
-#pragma unroll
-          for (int p = 0; p < FLM_COL_KT; p++)
-            if (p > q && src < 0 && m_rail[p]) src = 64 * p + __ffsll((long long)m_rail[p]) - 1;
-        }
-      }
-      if (src >= 0) {
-        const int rail = s_rail[src];
-        if (rail < Rp) v = rail * 2 + (s_dir[src] > 0 ? 1 : 0);
-      }
-    }
-    col[t] = (int16_t)v;
-  }
 }
 
 // Dense plane of every path from its column form: clear with 16-byte stores, then one byte per column.
@@ -904,4 +779,4 @@ extern "C" int flm_bitmaps_static(const int32_t* path_cell, const int32_t* path_
                      n_paths, H, W, capR, Rp, T1, plane_stride, Lcap, shift, ws, planes, err, stream);
 }
 
-extern "C" int flm_abi_version(void) { return 1; }
+extern "C" int flm_abi_version(void) { return 2; }

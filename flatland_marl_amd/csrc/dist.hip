@@ -9,30 +9,25 @@
 //     get "none");
 //   * each anchor gets up to four weighted edges to the anchors its moves lead to.
 // Per (environment, group of 32 distinct targets) (distance_chain_kernel): a label-correcting
-// shortest-path iteration over the few hundred anchors, all 32 targets side by side in LDS (sources: the
-// four states of the target cell at distance 0), then one coalesced pass writes
+// shortest-path iteration over the few hundred anchors (flm_sweep.h: one wave per four targets, the labels
+// of an anchor side by side in LDS; sources: the four states of the target cell at distance 0), then one
+// coalesced pass writes
 // dist[state] = steps[state] + dist[anchor of state].  The distances are the unique shortest move counts,
 // identical to a breadth-first search over the states, whatever the iteration order.
 #include "flm_common.h"
+#include "flm_sweep.h"
 
 namespace flm {
 
 #define FLM_NONE16 0xFFFFu
-
-// Orders the LDS accesses of one wave's lanes: a wave's LDS operations complete in program order, so it is
-// enough to keep the compiler from moving them across this point.
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-}
 
 __global__ __launch_bounds__(1024, 8) void chain_index_kernel(
     const uint16_t* __restrict__ grid_all, const int32_t* __restrict__ cell_idx_all,
     const int32_t* __restrict__ n_cells_all, const int32_t* __restrict__ target_cell, int A, int H, int W, int capCells,
     int capAnch, uint16_t* __restrict__ root_all, uint16_t* __restrict__ steps_all, uint32_t* __restrict__ edges_all,
     int32_t* __restrict__ n_anchor_all, int32_t* __restrict__ counts_all, uint16_t* __restrict__ succ_all,
-    uint16_t* __restrict__ choice_all) {
+    uint16_t* __restrict__ choice_all, uint16_t* __restrict__ walk_all, uint32_t* __restrict__ move_edge_all,
+    uint16_t* __restrict__ move_succ_all) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int e = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
   const int HW = H * W;
@@ -88,12 +83,14 @@ __global__ __launch_bounds__(1024, 8) void chain_index_kernel(
         nxt = nbr[n] * 4 + n;
       }
       const bool is_target = (flags[s >> 5] >> (s & 31)) & 1;
-      if (deg >= 2 && !is_target) atomicOr(&flags[s >> 5], 1u << (s & 31));
-      const bool anchor = is_target || deg >= 2;
       // forced step of a path walk: the heading allows exactly one exit (reported as "forward"), it leads to a
       // rail cell, and the cell is neither a dead end nor a target
+      const bool forced = !is_target && deg == 1 && __popc(nib) == 1 && __popc(code & 0xFFFFu) != 1;
+      // every live state that is not forced is an anchor: a walk only ever decides at anchors
+      const bool anchor = is_target || deg >= 2 || (deg == 1 && !forced);
+      if (anchor && !is_target) atomicOr(&flags[s >> 5], 1u << (s & 31));
       // (staged in the anchor-number array, which is not in use yet, and copied out with coalesced stores)
-      aidx[s] = (!is_target && deg == 1 && __popc(nib) == 1 && __popc(code & 0xFFFFu) != 1) ? (uint16_t)nxt : (uint16_t)FLM_NONE16;
+      aidx[s] = forced ? (uint16_t)nxt : (uint16_t)FLM_NONE16;
       if (choice_all && aidx[s] == FLM_NONE16) {
         // (only where the walk has no forced successor: it never looks at the other entries)
         // the moves a path walk may take from this state (get_valid_move_actions_: left, forward, right; in a
@@ -173,6 +170,15 @@ __global__ __launch_bounds__(1024, 8) void chain_index_kernel(
     const bool ok = aj != FLM_NONE16 && aj < (unsigned)capAnch;
     root[s] = ok ? (uint16_t)aj : (uint16_t)FLM_NONE16;
     steps[s] = ok ? sa[s] : 0;
+    if (walk_all) {
+      // what a path walk does in state s: a forced state names its successor, an anchor its own number
+      // (bit 15 set), a state without moves 0xFFFF.  The successor is the value this thread stored to succ above.
+      const unsigned own = aidx[s];
+      unsigned wv = FLM_NONE16;
+      if (own != FLM_NONE16) wv = own < (unsigned)capAnch && own < 0x7FFFu ? (0x8000u | own) : FLM_NONE16;
+      else wv = succ_all[(size_t)e * capS + s];
+      walk_all[(size_t)e * capS + s] = (uint16_t)wv;
+    }
   }
   // per anchor: one edge per move
   for (int cell = tid; cell < HW; cell += T) {
@@ -201,28 +207,43 @@ __global__ __launch_bounds__(1024, 8) void chain_index_kernel(
         out[k++] = aj | (w << 16);
       }
       reinterpret_cast<uint4*>(edges)[a] = make_uint4(out[0], out[1], out[2], out[3]);
+      if (move_edge_all) {
+        // the same edges in the order a path walk tries its moves (left, forward, right; in a dead end only the
+        // U-turn, in the forward slot) beside the states those moves lead to; the fourth entries hold the flag
+        // "the move is reported as forward" (a single exit, or the U-turn of a dead end)
+        uint32_t me[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        unsigned ms[3] = {FLM_NONE16, FLM_NONE16, FLM_NONE16};
+        const bool dead_end = __popc(code & 0xFFFFu) == 1;
+        for (int i = 0; i < 3; i++) {
+          const int d = dead_end ? ((h + 2) & 3) : ((h + i + 3) & 3);
+          if (dead_end && i != 1) continue;
+          if (!has_exit(nib, d)) continue;
+          const int nr = r + dr(d), nc = c + dc(d);
+          if (nr < 0 || nr >= H || nc < 0 || nc >= W) continue;
+          const int ni = cell_idx[nr * W + nc];
+          if (ni < 0) continue;
+          const int ns = ni * 4 + d;
+          ms[i] = (unsigned)ns;
+          const unsigned aj = aidx[ja[ns]];
+          if (aj == FLM_NONE16 || aj >= (unsigned)capAnch) continue;
+          me[i] = aj | ((1u + sa[ns]) << 16);
+        }
+        const unsigned single = (dead_end || __popc(nib) == 1) ? 1u : 0u;
+        reinterpret_cast<uint4*>(move_edge_all + (size_t)e * capAnch * 4)[a] = make_uint4(me[0], me[1], me[2], single);
+        reinterpret_cast<uint2*>(move_succ_all + (size_t)e * capAnch * 4)[a] =
+            make_uint2(ms[0] | (ms[1] << 16), ms[2] | (single << 16));
+      }
     }
   }
 }
 
-// One workgroup per (environment, 32 target slots).  LDS per anchor: its forward edges, its distance for
-// each of the 32 targets, its predecessors (reverse edges) and a 32-bit "dirty" set.  Targets are
-// independent problems, so each of the 16 waves owns 2 of them and iterates on its own, without workgroup
-// barriers (a wave's LDS operations complete in program order).  Per wave, work lists hold (anchor, target)
-// pairs packed in 16 bits.  A round has two phases, one lane per pair:
-//   1. every pair whose label got smaller marks the same target dirty at the anchor's predecessors; a
-//      pair that becomes dirty is appended once (the LDS atomic OR returns the previous set);
-//   2. every dirty pair re-evaluates its label as the minimum over the anchor's moves and, if it got
-//      smaller, is appended to the list of changed pairs.
-// Each label has one writer per round.  If a list ever fills up, the pairs that did not fit are made up
-// for after the rounds by sweeping all labels until nothing changes (labels are always lengths of real
-// paths, so the sweep converges to the same shortest distances).
+// One workgroup per (environment, 32 target slots).  LDS: the anchors' out-edges and, per group of four
+// targets, one 8-byte row of labels per anchor.  Targets are independent problems: wave g relaxes the labels
+// of targets 4g..4g+3 on its own (anchor_sweep, no workgroup barrier in the loop); then all waves write
+// dist[state] = steps[state] + label[anchor of state] with coalesced 16-byte stores.
 #define FLM_DC_THREADS 1024
-#define FLM_DC_LIST 256    // pairs per wave and list
-#ifndef FLM_DC_WAVES
-#define FLM_DC_WAVES 16     // waves that iterate (32 / FLM_DC_WAVES targets each); the other waves only help to set up and fill
-#endif
-#define FLM_DA_ROW 34   // uint16 per anchor row: 32 targets + 2 of padding, so that rows start on different LDS banks
+#define FLM_DC_TPG 4                      // targets per wave
+#define FLM_DC_GROUPS (32 / FLM_DC_TPG)   // waves that iterate; the others only help to set up and fill
 __global__ __launch_bounds__(FLM_DC_THREADS) void distance_chain_kernel(
     const uint16_t* __restrict__ root_all, const uint16_t* __restrict__ steps_all, const uint32_t* __restrict__ edges_all,
     const int32_t* __restrict__ n_anchor_all, const int32_t* __restrict__ n_cells_all,
@@ -230,8 +251,6 @@ __global__ __launch_bounds__(FLM_DC_THREADS) void distance_chain_kernel(
     const int32_t* __restrict__ n_slots, int A, int HW, int capCells, int capAnch, int ldsAnch,
     uint16_t* __restrict__ dist_all, int32_t* __restrict__ counts_all) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ int s_cnt[FLM_DC_THREADS / 64][2];   // per wave: changed-list size, dirty-list size
-  __shared__ int s_lost;                          // some pair did not fit a list
   const int e = blockIdx.y, tid = threadIdx.x, T = FLM_DC_THREADS;
   const int ns = n_slots[e];
   const int base_slot = blockIdx.x * 32;
@@ -244,184 +263,41 @@ __global__ __launch_bounds__(FLM_DC_THREADS) void distance_chain_kernel(
     if (tid == 0) atomicOr(&counts_all[e * 4 + 3], FLM_GRAPH_ERR_STATES);
     return;
   }
-  uint4* ed = reinterpret_cast<uint4*>(smem);                        // [ldsAnch] forward edges
-  uint16_t* da = reinterpret_cast<uint16_t*>(ed + ldsAnch);          // [ldsAnch][FLM_DA_ROW]
-  unsigned* dirty = reinterpret_cast<unsigned*>(da + (size_t)ldsAnch * FLM_DA_ROW);   // [ldsAnch]
-  unsigned* rev_off = dirty + ldsAnch;                               // [ldsAnch + 1]
-  uint16_t* rev_list = reinterpret_cast<uint16_t*>(rev_off + ldsAnch + 1);    // [4*ldsAnch]
-  uint16_t* lists = rev_list + 4 * (size_t)ldsAnch;                  // per wave: changed pairs, dirty pairs
+  uint4* ed = reinterpret_cast<uint4*>(smem);                                  // [ldsAnch] out-edges
+  unsigned* rows = reinterpret_cast<unsigned*>(ed + ldsAnch);                  // [FLM_DC_GROUPS][ldsAnch][2]
+  const uint16_t* lab = reinterpret_cast<const uint16_t*>(rows);               // the same labels, one by one
   const uint16_t* root = root_all + (size_t)e * capS;
   const uint16_t* steps = steps_all + (size_t)e * capS;
 
   for (int a = tid; a < NA; a += T) {
-    ed[a] = reinterpret_cast<const uint4*>(edges_all + (size_t)e * capAnch * 4)[a];
-    dirty[a] = 0;     // first used as in-degree counter / fill cursor while the reverse lists are built
+    uint4 ev = reinterpret_cast<const uint4*>(edges_all + (size_t)e * capAnch * 4)[a];
+    if (ev.x == FLM_NONE32) ev.x = (unsigned)a;      // a missing edge becomes a zero-weight loop
+    if (ev.y == FLM_NONE32) ev.y = (unsigned)a;
+    if (ev.z == FLM_NONE32) ev.z = (unsigned)a;
+    if (ev.w == FLM_NONE32) ev.w = (unsigned)a;
+    ed[a] = ev;
   }
-  for (int i = tid; i < NA * FLM_DA_ROW; i += T) da[i] = (uint16_t)FLM_NONE16;
-  if (tid < 2 * (T / 64)) (&s_cnt[0][0])[tid] = 0;
-  if (tid == 0) s_lost = 0;
+  for (int i = tid; i < FLM_DC_GROUPS * ldsAnch * 2; i += T) rows[i] = 0xFFFFFFFFu;
   __syncthreads();
-  // reverse adjacency (predecessor anchors)
-  for (int a = tid; a < NA; a += T) {
-    const uint4 eb = ed[a];
-    const unsigned ev[4] = {eb.x, eb.y, eb.z, eb.w};
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (ev[k] != 0xFFFFFFFFu) atomicAdd(&dirty[ev[k] & 0xFFFFu], 1u);
-  }
-  __syncthreads();
-  if (tid < 64) {   // exclusive scan of the in-degrees by one wave
-    unsigned carry = 0;
-    for (int base = 0; base < NA; base += 64) {
-      const int a = base + tid;
-      unsigned v = a < NA ? dirty[a] : 0, inc = v;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        unsigned t = __shfl_up(inc, o);
-        if (tid >= o) inc += t;
+  // sources: the four states of each target cell are anchors (root = own anchor number) at distance 0
+  if (tid < 4 * nslot) {
+    const int j = tid >> 2, h = tid & 3;
+    const int tcell = slot_target[(size_t)e * A + base_slot + j];
+    if (tcell >= 0 && tcell < HW) {
+      const int ci = cell_idx_all[(size_t)e * HW + tcell];
+      if (ci >= 0) {
+        const unsigned a = root[ci * 4 + h];
+        if (a != FLM_NONE16)
+          reinterpret_cast<uint16_t*>(rows)[((size_t)(j / FLM_DC_TPG) * ldsAnch + a) * FLM_DC_TPG + (j % FLM_DC_TPG)] = 0;
       }
-      if (a < NA) rev_off[a] = carry + inc - v;
-      carry += __shfl(inc, 63);
     }
-    if (tid == 0) rev_off[NA] = carry;
   }
-  __syncthreads();
-  for (int a = tid; a < NA; a += T) dirty[a] = 0;
-  __syncthreads();
-  for (int a = tid; a < NA; a += T) {
-    const uint4 eb = ed[a];
-    const unsigned ev[4] = {eb.x, eb.y, eb.z, eb.w};
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (ev[k] != 0xFFFFFFFFu) {
-        const unsigned t = ev[k] & 0xFFFFu;
-        rev_list[rev_off[t] + atomicAdd(&dirty[t], 1u)] = (uint16_t)a;
-      }
-  }
-  __syncthreads();
-  for (int a = tid; a < NA; a += T) dirty[a] = 0;
   __syncthreads();
   {
     const int w = tid >> 6, lane = tid & 63;
-    uint16_t* lc = lists + (size_t)(w < FLM_DC_WAVES ? w : 0) * 2 * FLM_DC_LIST;   // changed pairs
-    uint16_t* ld = lc + FLM_DC_LIST;                      // dirty pairs
-    int* cnt = s_cnt[w];
-    // sources: the four states of each target cell (this wave's targets are w, w + FLM_DC_WAVES, ...)
-    if (w < FLM_DC_WAVES && lane < 4 * (32 / FLM_DC_WAVES)) {
-      const int j = w + FLM_DC_WAVES * (lane >> 2), h = lane & 3;
-      if (j < nslot) {
-        const int tcell = slot_target[(size_t)e * A + base_slot + j];
-        if (tcell >= 0 && tcell < HW) {
-          const int ci = cell_idx_all[(size_t)e * HW + tcell];
-          if (ci >= 0) {
-            const unsigned a = root[ci * 4 + h];   // target states are anchors: root = own anchor number
-            if (a != FLM_NONE16) {
-              da[a * FLM_DA_ROW + j] = 0;
-              lc[atomicAdd(&cnt[0], 1)] = (uint16_t)(a | (j << 11));
-            }
-          }
-        }
-      }
-    }
-    wave_sync();
-    // list sizes live in (wave-uniform) registers; appends are placed by ballot ranks, so the only LDS
-    // atomics left are the dirty-set updates, which rarely meet on one address
-    int n_c = w < FLM_DC_WAVES ? min(cnt[0], FLM_DC_LIST) : 0;
-    for (int round = 0; round < 65536; round++) {
-      if (n_c == 0) break;
-      // phase 1: predecessors of the changed pairs become dirty
-      int n_d = 0;
-      for (int base = 0; base < n_c; base += 64) {
-        const int i = base + lane;
-        const bool have = i < n_c;
-        const unsigned pr = have ? lc[i] : 0u;
-        const unsigned r = pr & 0x7FFu, bit = 1u << (pr >> 11);
-        unsigned q = have ? rev_off[r] : 0u;
-        const unsigned qe = have ? rev_off[r + 1] : 0u;
-        while (__ballot(q < qe)) {
-          bool fresh = false;
-          unsigned bb = 0;
-          if (q < qe) {
-            bb = rev_list[q++];
-            fresh = !(atomicOr(&dirty[bb], bit) & bit);
-          }
-          const unsigned long long mk = __ballot(fresh);
-          if (fresh) {
-            const int pos = n_d + __popcll(mk & lanemask_lt());
-            if (pos < FLM_DC_LIST) ld[pos] = (uint16_t)(bb | (pr & 0xF800u));
-            else s_lost = 1;
-          }
-          n_d += __popcll(mk);
-        }
-      }
-      wave_sync();
-      const int nd = min(n_d, FLM_DC_LIST);
-      // phase 2: re-evaluate the dirty pairs; the changed list has been consumed and is refilled
-      n_c = 0;
-      for (int base = 0; base < nd; base += 64) {
-        const int i = base + lane;
-        bool improved = false;
-        unsigned pr = 0;
-        if (i < nd) {
-          pr = ld[i];
-          const unsigned bb = pr & 0x7FFu, j = pr >> 11;
-          const uint4 eb = ed[bb];
-          const unsigned ev[4] = {eb.x, eb.y, eb.z, eb.w};
-          const unsigned cur = da[bb * FLM_DA_ROW + j];
-          unsigned best = cur;
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            if (ev[k] == 0xFFFFFFFFu) continue;
-            const unsigned d = da[(ev[k] & 0xFFFFu) * FLM_DA_ROW + j];
-            if (d == FLM_NONE16) continue;
-            const unsigned cand = d + (ev[k] >> 16);
-            if (cand < best) best = cand;
-          }
-          atomicAnd(&dirty[bb], ~(1u << j));
-          if (best < cur) {
-            da[bb * FLM_DA_ROW + j] = (uint16_t)(best > 0xFFFEu ? 0xFFFEu : best);
-            improved = true;
-          }
-        }
-        const unsigned long long mk = __ballot(improved);
-        if (improved) {
-          const int pos = n_c + __popcll(mk & lanemask_lt());
-          if (pos < FLM_DC_LIST) lc[pos] = (uint16_t)pr;
-          else s_lost = 1;
-        }
-        n_c += __popcll(mk);
-      }
-      n_c = min(n_c, FLM_DC_LIST);
-      wave_sync();
-    }
+    if (w * FLM_DC_TPG < nslot) anchor_sweep<FLM_DC_TPG / 2>(rows + (size_t)w * ldsAnch * (FLM_DC_TPG / 2), ed, NA, lane);
   }
   __syncthreads();
-  if (s_lost) {
-    // some pairs did not fit a list: sweep all labels until none changes
-    const int j = tid & 31;
-    for (int it = 0; it <= NA * 32; it++) {
-      int changed = 0;
-      for (int b = tid >> 5; b < NA; b += (T >> 5)) {
-        const uint4 eb = ed[b];
-        const unsigned ev[4] = {eb.x, eb.y, eb.z, eb.w};
-        const unsigned cur = da[b * FLM_DA_ROW + j];
-        unsigned best = cur;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          if (ev[k] == 0xFFFFFFFFu) continue;
-          const unsigned d = da[(ev[k] & 0xFFFFu) * FLM_DA_ROW + j];
-          if (d == FLM_NONE16) continue;
-          const unsigned cand = d + (ev[k] >> 16);
-          if (cand < best) best = cand;
-        }
-        if (best < cur) {
-          da[b * FLM_DA_ROW + j] = (uint16_t)(best > 0xFFFEu ? 0xFFFEu : best);
-          changed = 1;
-        }
-      }
-      if (!__syncthreads_or(changed)) break;
-    }
-  }
   // every state: steps to its anchor + the anchor's distance.  A thread owns 8 consecutive states and
   // writes them to each target's row with one 16-byte store (rows are 16-byte aligned: capCells is even).
   for (int s0 = tid * 8; s0 < S; s0 += T * 8) {
@@ -438,12 +314,13 @@ __global__ __launch_bounds__(FLM_DC_THREADS) void distance_chain_kernel(
     }
     uint16_t* dist = dist_all + ((size_t)e * A + base_slot) * capS + s0;
     for (int jj = 0; jj < nslot; jj++) {
+      const uint16_t* col = lab + (size_t)(jj / FLM_DC_TPG) * ldsAnch * FLM_DC_TPG + (jj % FLM_DC_TPG);
       unsigned d[8];
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         unsigned v = FLM_NONE16;
         if (an[i] != FLM_NONE16 && s0 + i < S) {
-          const unsigned d0 = da[an[i] * FLM_DA_ROW + jj];
+          const unsigned d0 = col[an[i] * FLM_DC_TPG];
           if (d0 != FLM_NONE16) {
             v = d0 + st[i];
             if (v > 0xFFFEu) v = 0xFFFEu;
@@ -462,8 +339,11 @@ __global__ __launch_bounds__(FLM_DC_THREADS) void distance_chain_kernel(
 extern "C" int flm_chain_index(const uint16_t* grid, const int32_t* cell_idx, const int32_t* n_cells,
                                const int32_t* target_cell, int E, int A, int H, int W, int capCells, int capAnch,
                                uint16_t* root, uint16_t* steps, uint32_t* edges, int32_t* n_anchor, int32_t* counts,
-                               uint16_t* succ, uint16_t* choice, void* stream) {
+                               uint16_t* succ, uint16_t* choice, uint16_t* walk, uint32_t* move_edge, uint16_t* move_succ,
+                               void* stream) {
   if (!grid || !cell_idx || !n_cells || !target_cell || !root || !steps || !edges || !n_anchor || !counts) return FLM_E_ARG;
+  if ((walk || move_edge || move_succ) && !(walk && move_edge && move_succ && succ)) return FLM_E_ARG;   // all or none
+  if (walk && capCells * 4 > 32768) return FLM_E_ARG;   // bit 15 of a walk entry marks an anchor
   if (E <= 0 || A <= 0 || H <= 0 || W <= 0 || capCells <= 0 || capCells * 4 >= 65535 || capAnch <= 0 || capAnch > 0xFFF0)
     return FLM_E_ARG;
   const size_t capS = (size_t)capCells * 4;
@@ -473,7 +353,8 @@ extern "C" int flm_chain_index(const uint16_t* grid, const int32_t* cell_idx, co
                           (int)lds) != hipSuccess)
     return FLM_E_LAUNCH;
   hipLaunchKernelGGL(flm::chain_index_kernel, dim3(E), dim3(1024), lds, (hipStream_t)stream, grid, cell_idx, n_cells,
-                     target_cell, A, H, W, capCells, capAnch, root, steps, edges, n_anchor, counts, succ, choice);
+                     target_cell, A, H, W, capCells, capAnch, root, steps, edges, n_anchor, counts, succ, choice, walk,
+                     move_edge, move_succ);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }
@@ -488,9 +369,8 @@ extern "C" int flm_distance_chains(const uint16_t* root, const uint16_t* steps, 
   if (E <= 0 || E > 65535 || A <= 0 || H <= 0 || W <= 0 || capCells <= 0 || capAnch <= 0 || ldsAnch <= 0 ||
       ldsAnch > capAnch)
     return FLM_E_ARG;
-  if (ldsAnch > 2047) return FLM_E_ARG;   // anchors are packed in 11 bits on the work lists
   if (capCells & 1) return FLM_E_ARG;     // 16-byte row stores
-  size_t lds = (size_t)ldsAnch * (16 + 2 * FLM_DA_ROW + 4 + 4 + 8) + 16 + FLM_DC_WAVES * 2 * FLM_DC_LIST * 2;
+  size_t lds = (size_t)ldsAnch * (16 + 32 * 2);
   if (lds > 160 * 1024 - 512) return FLM_E_ARG;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(flm::distance_chain_kernel),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

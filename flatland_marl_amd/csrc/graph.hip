@@ -199,7 +199,8 @@ __global__ __launch_bounds__(1024, 8) void graph_build_kernel(
 // Compact numbering of rail cells + (optionally) the reverse-move table, one 1024-thread workgroup per environment.
 __global__ __launch_bounds__(1024) void state_index_kernel(const uint16_t* __restrict__ grid_all, int H, int W, int capCells,
                                                            int32_t* __restrict__ cell_idx_all, int32_t* __restrict__ n_cells_all,
-                                                           uint16_t* __restrict__ pred_all, int32_t* __restrict__ counts_all) {
+                                                           uint16_t* __restrict__ pred_all, int32_t* __restrict__ counts_all,
+                                                           int32_t* __restrict__ idx_cell_all) {
   __shared__ int wave_tot[16];
   const int e = blockIdx.x, tid = threadIdx.x, HW = H * W;
   const int wave = tid >> 6;
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(1024) void state_index_kernel(const uint16_t* __res
     __syncthreads();
     const int id = n + before + __popcll(m & lanemask_lt());
     if (cell < HW) cell_idx[cell] = (rail && id < capCells) ? id : -1;
+    if (idx_cell_all && rail && id < capCells) idx_cell_all[(size_t)e * capCells + id] = cell;
     n += tot;
   }
   if (tid == 0) {
@@ -286,11 +288,11 @@ extern "C" int flm_graph_build(const uint16_t* grid, int E, int H, int W, int ca
 }
 
 extern "C" int flm_state_index(const uint16_t* grid, int E, int H, int W, int capCells, int32_t* cell_idx,
-                               int32_t* n_cells, uint16_t* pred, int32_t* counts, void* stream) {
+                               int32_t* n_cells, uint16_t* pred, int32_t* counts, int32_t* idx_cell, void* stream) {
   if (!grid || !cell_idx || !n_cells || !counts) return FLM_E_ARG;   // pred may be NULL: numbering only
   if (E <= 0 || H <= 0 || W <= 0 || capCells <= 0 || capCells * 4 >= 65535) return FLM_E_ARG;
   hipLaunchKernelGGL(flm::state_index_kernel, dim3(E), dim3(1024), 0, (hipStream_t)stream, grid, H, W, capCells,
-                     cell_idx, n_cells, pred, counts);
+                     cell_idx, n_cells, pred, counts, idx_cell);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }

@@ -75,9 +75,10 @@ int flm_graph_build(const uint16_t* grid, int E, int H, int W, int capN, int cap
  *   cell_idx [E,H*W] int32 (-1 = empty cell), n_cells [E] int32,
  *   pred     [E,capCells*4,4] uint16: for state cell_idx*4+heading, the states that reach it in one move
  *            (0xFFFF = none); NULL = numbering only (the chain-compressed distances do not need it).
- *            capCells*4 < 65535.  counts[e*4+3] gets FLM_GRAPH_ERR_STATES on overflow. */
+ *            capCells*4 < 65535.  counts[e*4+3] gets FLM_GRAPH_ERR_STATES on overflow.
+ *   idx_cell [E,capCells] int32 (may be NULL) out: the cell of each compact number (the inverse of cell_idx). */
 int flm_state_index(const uint16_t* grid, int E, int H, int W, int capCells, int32_t* cell_idx,
-                    int32_t* n_cells, uint16_t* pred, int32_t* counts, void* stream);
+                    int32_t* n_cells, uint16_t* pred, int32_t* counts, int32_t* idx_cell, void* stream);
 
 /* Distance of every (cell, heading) state to each agent's target, one BFS per distinct target.
  * Replaces flatland DistanceMap.get() as called at src/utils/shortest_path.py:60-62.
@@ -106,15 +107,24 @@ int flm_distance_bfs(const uint16_t* pred, const int32_t* cell_idx, const int32_
  *                      a dead end sits in the forward slot) and 1 when the move is reported as forward
  *                      (src/utils/shortest_path.py:56-57 through get_valid_move_actions_), so that a walk reads
  *                      one entry where it has a choice; written only for states whose succ is 0xFFFF;
+ *                      walk [E,capCells*4] uint16, move_edge [E,capAnch,4] uint32, move_succ [E,capAnch,4] uint16
+ *                      (all three or none; they need succ and capCells*4 <= 32768) out: the tables of
+ *                      flm_paths_columns: walk = the successor of a forced state, 0x8000 | anchor number for an
+ *                      anchor, 0xFFFF for a state without moves; move_edge = an anchor's edges (anchor |
+ *                      weight<<16, 0xFFFFFFFF = none) in the order a walk tries its moves (left, forward, right;
+ *                      the U-turn of a dead end in the forward slot), fourth entry 1 when the move is reported
+ *                      as forward; move_succ = the states those moves lead to, fourth entry the same flag.
+ *                      Anchors are the states with two or more moves, the states on target cells, and the
+ *                      states with one move that a walk does not treat as forced;
  *   flm_distance_chains  dist [E,A,capCells*4] as flm_distance_bfs; ldsAnch <= capAnch is the number of
- *                      anchors the workgroup's LDS tables are sized for (100 bytes each plus 16 KiB of work lists, 2047 at
- *                      most); an environment
+ *                      anchors the workgroup's LDS tables are sized for (80 bytes each); an environment
  *                      with more anchors is flagged in counts[e*4+3] and its rows are left unwritten. */
 int flm_target_slots(const int32_t* target_cell, int E, int A, int32_t* tslot, int32_t* n_slots, int32_t* slot_target,
                      void* stream);
 int flm_chain_index(const uint16_t* grid, const int32_t* cell_idx, const int32_t* n_cells, const int32_t* target_cell,
                     int E, int A, int H, int W, int capCells, int capAnch, uint16_t* root, uint16_t* steps,
-                    uint32_t* edges, int32_t* n_anchor, int32_t* counts, uint16_t* succ, uint16_t* choice, void* stream);
+                    uint32_t* edges, int32_t* n_anchor, int32_t* counts, uint16_t* succ, uint16_t* choice,
+                    uint16_t* walk, uint32_t* move_edge, uint16_t* move_succ, void* stream);
 int flm_distance_chains(const uint16_t* root, const uint16_t* steps, const uint32_t* edges, const int32_t* n_anchor,
                         const int32_t* n_cells, const int32_t* cell_idx, const int32_t* slot_target,
                         const int32_t* n_slots, int E, int A, int H, int W, int capCells, int capAnch, int ldsAnch,
@@ -133,6 +143,36 @@ int flm_shortest_paths(const uint16_t* grid, const int32_t* cell_idx, const uint
                        const int32_t* target_cell, const int32_t* status, int E, int A, int H, int W,
                        int capCells, int max_depth, int Lcap, int32_t* path_cell, uint32_t* path_meta,
                        int32_t* path_len, void* stream);
+
+/* flm_shortest_paths + flm_columns of every agent from the chain index alone: the dense distance map of
+ * flm_distance_chains is not needed (anchor distances, the walks and the column scans stay in LDS; two
+ * launches hand each other two bits per (anchor, target): the move a walk takes there).  Replaces what env.reset() makes get_many compute:
+ * ShortestPathPredictorForRailEnv.get -> get_shortest_paths (src/predictions.py:36-72,
+ * src/utils/shortest_path.py:11-90, with flatland's DistanceMap.get() as used at :60-62), prediction_from_path
+ * (src/predictions.py:85-143), _bitmap_from_cells_seq and the shift (src/rail_observations.py:78-95, 323-407).
+ *   walk, root, steps, edges, move_edge, move_succ, n_anchor: tables of flm_chain_index; tslot / n_slots / slot_target of
+ *   flm_target_slots; cell_idx / idx_cell / n_cells of flm_state_index; cell_rail / node_id / edge_info of
+ *   flm_graph_build;
+ *   start_cell / start_dir / status as flm_shortest_paths, pos_cell / tpc as flm_columns (all [E,A]);
+ *   ldsAnch / ldsSlots (a multiple of 8): anchors and distinct targets per environment the LDS tables are sized
+ *   for; an environment with more is flagged in counts[e*4+3] (FLM_GRAPH_ERR_STATES) and its outputs are left
+ *   unwritten; flm_paths_columns_lds_bytes gives the LDS bytes a launch needs (FLM_E_CAPACITY above 159.5 KiB);
+ *   workspace: flm_paths_columns_workspace(E, A, ldsAnch, ldsSlots) int32 words;
+ *   path_cell / path_meta [E,A,Lcap] (both or neither; NULL = paths are not stored), path_len [E,A], cols
+ *   [E,A,T1], err [E,A]: exactly what flm_shortest_paths followed by flm_columns write.
+ * H, W <= 256, capCells*4 <= 32768, T1 <= 512, Lcap >= max_depth + 1. */
+long flm_paths_columns_lds_bytes(int A, int capCells, int ldsAnch, int ldsSlots, int capR, int Lcap, int T1);
+long flm_paths_columns_workspace(int E, int A, int ldsAnch, int ldsSlots);   /* int32 words */
+int flm_paths_columns(const uint16_t* walk, const uint16_t* root, const uint16_t* steps, const uint32_t* edges,
+                      const uint32_t* move_edge,
+                      const uint16_t* move_succ, const int32_t* n_anchor, const int32_t* n_cells,
+                      const int32_t* cell_idx, const int32_t* idx_cell, const int32_t* cell_rail, const int32_t* node_id,
+                      const int32_t* edge_info, const int32_t* tslot, const int32_t* n_slots,
+                      const int32_t* slot_target, const int32_t* start_cell, const int32_t* start_dir,
+                      const int32_t* pos_cell, const int32_t* target_cell, const int32_t* status, const int32_t* tpc,
+                      int E, int A, int H, int W, int capCells, int capAnch, int ldsAnch, int ldsSlots, int capR, int Rp,
+                      int T1, int max_depth, int Lcap, int shift, int32_t* workspace, int32_t* path_cell,
+                      uint32_t* path_meta, int32_t* path_len, int16_t* cols, int32_t* err, int32_t* counts, void* stream);
 
 /* Path -> predicted cell per time step -> rail-occupancy plane, optionally moved one step to the right.
  * Replaces prediction_from_path + cells_seq_from_prediction, src/predictions.py:85-143,
