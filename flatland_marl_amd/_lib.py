@@ -52,11 +52,11 @@ _SIGNATURES = {
     "flm_dqn_forward_workspace": [_i, _i],
     "flm_dqn_learn_workspace": [_i, _i, _i],
     "flm_dqn_learn_workspace_u8": [_i, _i, _i],
-    "flm_dqn_learn_grads_u8": [_p, _p, _p, _p, _i, _p, _p, _p, C.c_float, _i, _i, _i, _p, _p, _p, _p],
+    "flm_dqn_learn_grads_u8": [_p, _p, _p, _p, _i, _p, _p, _p, C.c_float, _i, _i, _i, _i, _p, _p, _p, _p],
     "flm_dqn_forward": [_p, _p, _i, _i, _i, _p, _p, _p],
     "flm_obs_to_f32": [_p, _i, _i, _i, _i, _p, _p],
     "flm_dqn_forward_u8": [_p, _p, _i, _i, _i, _i, _p, _p, _p],
-    "flm_dqn_learn_grads": [_p, _p, _p, _p, _p, _p, _p, C.c_float, _i, _i, _i, _p, _p, _p, _p],
+    "flm_dqn_learn_grads": [_p, _p, _p, _p, _p, _p, _p, C.c_float, _i, _i, _i, _i, _p, _p, _p, _p],
     "flm_dqn_adam": [_p, _p, _p, _p, C.c_long, C.c_double, C.c_double, C.c_double, C.c_double, _i, _p],
     "flm_dqn_soft_update": [_p, _p, C.c_long, C.c_double, _p],
     "flm_dqn_adam_soft_update": [_p, _p, _p, _p, _p, C.c_long, C.c_double, C.c_double, C.c_double, C.c_double, _i,

@@ -66,8 +66,6 @@ class DQNAgent:
         self.height = bitmap_height
         self.action_space = action_space
         self.double_dqn = double_dqn
-        if not double_dqn:
-            raise NotImplementedError("only the double-DQN target (the reference's default) is implemented")
         self.qnetwork_local = Dueling_DQN(self.width, self.height, action_space).to(device)
         self.qnetwork_target = copy.deepcopy(self.qnetwork_local)
         self.optimizer = FlatAdam(self.qnetwork_local, lr=self.args.lr)
@@ -120,8 +118,8 @@ class DQNAgent:
         d = dones.to(dev, torch.float32).contiguous()
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         self.optimizer.zero_grad()
-        call("flm_dqn_learn_grads", ptr(local), ptr(target), ptr(s), ptr(sn), ptr(a), ptr(r), ptr(d), float(gamma), B,
-             self.height, self.width, ptr(self._ws), ptr(self.optimizer.grads), ptr(loss),
+        call("flm_dqn_learn_grads", ptr(local), ptr(target), ptr(s), ptr(sn), ptr(a), ptr(r), ptr(d), float(gamma),
+             1 if self.double_dqn else 0, B, self.height, self.width, ptr(self._ws), ptr(self.optimizer.grads), ptr(loss),
              torch.cuda.current_stream(dev).cuda_stream)
         parallel.allreduce_mean_(self.optimizer.grads)      # data parallel: one bucket, RCCL over xGMI
         self.last_loss = loss
@@ -150,7 +148,7 @@ class DQNAgent:
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         self.optimizer.zero_grad()
         call("flm_dqn_learn_grads_u8", ptr(local), ptr(target), ptr(s), ptr(sn), int(plane_stride), ptr(a), ptr(r), ptr(d),
-             float(gamma), B, Rp, self.width, ptr(self._ws), ptr(self.optimizer.grads), ptr(loss),
+             float(gamma), 1 if self.double_dqn else 0, B, Rp, self.width, ptr(self._ws), ptr(self.optimizer.grads), ptr(loss),
              torch.cuda.current_stream(dev).cuda_stream)
         parallel.allreduce_mean_(self.optimizer.grads)      # data parallel: one bucket, RCCL over xGMI
         self.last_loss = loss

@@ -364,6 +364,47 @@ __global__ void td_loss_kernel(const float* __restrict__ q, const float* __restr
   dq[b * 2 + (1 - a)] = 0.f;
 }
 
+// The reference's target without double DQN (src/agent.py:103-105).  Its Q_targets_next keeps a trailing axis
+// of length one, so rewards + gamma * Q_targets_next * (1 - dones) is a [B,B] matrix, target[i,j] = r[j] +
+// gamma * max_a q_next_target[i,a] * (1 - done[j]), and mse_loss compares q[j,action[j]] with every row i of
+// column j: loss = mean over (i,j) of (q_j - target[i,j])^2.  In closed form, with m1 / m2 the batch means of
+// the maxima and of their squares, u_j = q_j - r_j and c_j = gamma * (1 - done[j]):
+//   loss = mean_j (u_j^2 - 2 u_j c_j m1 + c_j^2 m2),   dloss/dq_j = 2 (u_j - c_j m1) / B.
+// One workgroup: the two means in a fixed order, then one thread per sample.
+__global__ __launch_bounds__(1024) void td_loss_plain_kernel(const float* __restrict__ q, const float* __restrict__ q_next_target,
+                                                             const int64_t* __restrict__ action,
+                                                             const float* __restrict__ reward, const float* __restrict__ done,
+                                                             float gamma, int B, float* __restrict__ dq,
+                                                             float* __restrict__ sq_err) {
+  __shared__ double s1[1024], s2[1024];
+  const int tid = threadIdx.x;
+  double a1 = 0.0, a2 = 0.0;
+  for (int b = tid; b < B; b += 1024) {
+    const float m = fmaxf(q_next_target[b * 2], q_next_target[b * 2 + 1]);
+    a1 += (double)m;
+    a2 += (double)m * (double)m;
+  }
+  s1[tid] = a1;
+  s2[tid] = a2;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o) {
+      s1[tid] += s1[tid + o];
+      s2[tid] += s2[tid + o];
+    }
+    __syncthreads();
+  }
+  const float m1 = (float)(s1[0] / (double)B), m2 = (float)(s2[0] / (double)B);
+  for (int b = tid; b < B; b += 1024) {
+    const int a = (int)action[b];
+    const float u = q[b * 2 + a] - reward[b];
+    const float c = gamma * (1.f - done[b]);
+    sq_err[b] = u * u - 2.f * u * c * m1 + c * c * m2;
+    dq[b * 2 + a] = 2.f * (u - c * m1) / (float)B;
+    dq[b * 2 + (1 - a)] = 0.f;
+  }
+}
+
 __global__ __launch_bounds__(64) void mean_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
   float s = 0.f;
   for (int i = threadIdx.x; i < n; i += 64) s += x[i];
@@ -848,8 +889,8 @@ extern "C" long flm_dqn_learn_workspace(int B, int H3, int T1) {
 // gradient needs.
 static int learn_grads_impl(const float* local, const float* target, const float* s, const float* s_next,
                             const uint8_t* s_u8, const uint8_t* sn_u8, int plane_stride, const int64_t* action,
-                            const float* reward, const float* done, float gamma, int B, int H3, int T1, float* ws,
-                            float* grads, float* loss_out, hipStream_t stream) {
+                            const float* reward, const float* done, float gamma, int double_dqn, int B, int H3, int T1,
+                            float* ws, float* grads, float* loss_out, hipStream_t stream) {
   DqnLayout L(H3, T1);
   const long n_x1 = (long)B * 64 * H3, n_hid = (long)B * 1024;
   float* x1 = ws;            float* hid = x1 + n_x1;
@@ -869,12 +910,18 @@ static int learn_grads_impl(const float* local, const float* target, const float
     if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   }
   if ((rc = dqn_forward_impl(local, s_u8 ? nullptr : s, s_u8, plane_stride, B, H3, T1, x1, hid, part, q, stream))) return rc;
-  if ((rc = dqn_forward_impl(local, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, x1n, hidn, part, qn, stream)))
+  // the local network's view of the next states picks the action only under double DQN
+  if (double_dqn &&
+      (rc = dqn_forward_impl(local, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, x1n, hidn, part, qn, stream)))
     return rc;
   if ((rc = dqn_forward_impl(target, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, x1t, hidt, part, qt, stream)))
     return rc;
-  hipLaunchKernelGGL(flm::td_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, q, qn, qt, action, reward, done, gamma,
-                     B, dq, sq);
+  if (double_dqn)
+    hipLaunchKernelGGL(flm::td_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, q, qn, qt, action, reward, done,
+                       gamma, B, dq, sq);
+  else
+    hipLaunchKernelGGL(flm::td_loss_plain_kernel, dim3(1), dim3(1024), 0, stream, q, qt, action, reward, done, gamma, B, dq,
+                       sq);
   hipLaunchKernelGGL(flm::mean_kernel, dim3(1), dim3(64), 0, stream, sq, B, loss_out);
   // head
   hipLaunchKernelGGL(flm::head_backward_hidden_kernel, dim3(B), dim3(64), 0, stream, hid, dq, local + L.a2_w, local + L.v2_w, B,
@@ -919,12 +966,13 @@ static int learn_grads_impl(const float* local, const float* target, const float
 }
 
 extern "C" int flm_dqn_learn_grads(const float* local, const float* target, const float* s, const float* s_next,
-                                   const int64_t* action, const float* reward, const float* done, float gamma, int B,
-                                   int H3, int T1, float* ws, float* grads, float* loss_out, void* stream) {
+                                   const int64_t* action, const float* reward, const float* done, float gamma,
+                                   int double_dqn, int B, int H3, int T1, float* ws, float* grads, float* loss_out,
+                                   void* stream) {
   if (!local || !target || !s || !s_next || !action || !reward || !done || !ws || !grads || !loss_out) return FLM_E_ARG;
   if (B <= 0 || H3 <= 0 || T1 <= 0) return FLM_E_ARG;
-  return learn_grads_impl(local, target, s, s_next, nullptr, nullptr, 0, action, reward, done, gamma, B, H3, T1, ws, grads,
-                          loss_out, (hipStream_t)stream);
+  return learn_grads_impl(local, target, s, s_next, nullptr, nullptr, 0, action, reward, done, gamma, double_dqn, B, H3, T1,
+                          ws, grads, loss_out, (hipStream_t)stream);
 }
 
 extern "C" long flm_dqn_learn_workspace_u8(int B, int Rp, int T1) {
@@ -933,14 +981,14 @@ extern "C" long flm_dqn_learn_workspace_u8(int B, int Rp, int T1) {
 
 extern "C" int flm_dqn_learn_grads_u8(const float* local, const float* target, const uint8_t* s, const uint8_t* s_next,
                                       int plane_stride, const int64_t* action, const float* reward, const float* done,
-                                      float gamma, int B, int Rp, int T1, float* ws, float* grads, float* loss_out,
-                                      void* stream) {
+                                      float gamma, int double_dqn, int B, int Rp, int T1, float* ws, float* grads,
+                                      float* loss_out, void* stream) {
   if (!local || !target || !s || !s_next || !action || !reward || !done || !ws || !grads || !loss_out) return FLM_E_ARG;
   if (B <= 0 || Rp <= 0 || T1 <= 0 || (long)plane_stride < (long)Rp * T1) return FLM_E_ARG;
   const int H3 = 3 * Rp;
   float* s_f32 = ws + flm_dqn_learn_workspace(B, H3, T1);     // the float copy of s lives behind the common workspace
-  return learn_grads_impl(local, target, s_f32, nullptr, s, s_next, plane_stride, action, reward, done, gamma, B, H3, T1, ws,
-                          grads, loss_out, (hipStream_t)stream);
+  return learn_grads_impl(local, target, s_f32, nullptr, s, s_next, plane_stride, action, reward, done, gamma, double_dqn, B,
+                          H3, T1, ws, grads, loss_out, (hipStream_t)stream);
 }
 
 extern "C" int flm_dqn_adam(float* params, const float* grads, float* m, float* v, long n, double lr, double beta1,

@@ -389,14 +389,17 @@ int flm_dqn_forward_u8(const float* params, const uint8_t* obs, int n, int Rp, i
 /* uint8 observations [n,3,plane_stride] (own plane int8) -> float rows [n,3*Rp,T1], the network's input. */
 int flm_obs_to_f32(const uint8_t* obs, int n, int Rp, int T1, int plane_stride, float* out, void* stream);
 
-/* One learn step up to the gradient (src/agent.py:94-114, double DQN): three forward passes, the
- * mean-squared TD error (loss_out[1]) and its gradient w.r.t. the local network (grads, flat layout).
+/* One learn step up to the gradient (src/agent.py:94-114): the forward passes, the mean-squared TD error
+ * (loss_out[1]) and its gradient w.r.t. the local network (grads, flat layout).  double_dqn != 0: the action of
+ * the next state is the local network's, its value the target network's (:98-101); double_dqn == 0: the
+ * reference's plain-DQN branch (:103-105) as it really computes - its next-state maxima keep a trailing axis, so
+ * every sample is compared with the targets built from every sample's maximum ([B,B] broadcast inside mse_loss).
  * action int64 [B], reward/done float [B].  workspace: flm_dqn_learn_workspace floats.
  * The reference also back-propagates into the target network (its Q_targets are not detached); those
  * gradients are never used by the optimizer and are not computed here. */
 int flm_dqn_learn_grads(const float* local, const float* target, const float* s, const float* s_next,
-                        const int64_t* action, const float* reward, const float* done, float gamma, int B, int H3,
-                        int T1, float* workspace, float* grads, float* loss_out, void* stream);
+                        const int64_t* action, const float* reward, const float* done, float gamma, int double_dqn,
+                        int B, int H3, int T1, float* workspace, float* grads, float* loss_out, void* stream);
 
 /* The same learn step on uint8 observations [B,3,plane_stride] as stored by a device replay memory: the
  * forward passes read the bytes; only the states s are expanded to float (inside the workspace) for the
@@ -404,7 +407,8 @@ int flm_dqn_learn_grads(const float* local, const float* target, const float* s,
 long flm_dqn_learn_workspace_u8(int B, int Rp, int T1);
 int flm_dqn_learn_grads_u8(const float* local, const float* target, const uint8_t* s, const uint8_t* s_next,
                            int plane_stride, const int64_t* action, const float* reward, const float* done, float gamma,
-                           int B, int Rp, int T1, float* workspace, float* grads, float* loss_out, void* stream);
+                           int double_dqn, int B, int Rp, int T1, float* workspace, float* grads, float* loss_out,
+                           void* stream);
 
 /* torch.optim.Adam step with default options over flat buffers (src/agent.py:38,113-115); step counts from 1. */
 int flm_dqn_adam(float* params, const float* grads, float* m, float* v, long n, double lr, double beta1, double beta2,

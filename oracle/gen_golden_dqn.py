@@ -70,5 +70,52 @@ def main():
         print(k, v.shape, v.ravel()[:4])
 
 
+def main_plain():
+    """One learn step of the reference's agent with double_dqn=False (src/agent.py:103-105) -> dqn_reference_plain.npz.
+    Its Q_targets_next keeps a trailing axis of length one, so the targets broadcast to [B,B] against the [B]
+    expected values inside mse_loss (torch warns about the sizes): what is recorded here is that behaviour."""
+    import warnings
+    out = {}
+    H3 = 3 * dqn_inputs.MAX_RAILS
+    B = 16
+    args = argparse.Namespace(prediction_depth=dqn_inputs.DEPTH, lr=0.00005, buffer_size=100, batch_size=B,
+                              update_every=10, gamma=0.99, tau=1e-3)
+    torch.manual_seed(4321)
+    agent = DQNAgent(args, action_space=2, bitmap_height=H3, double_dqn=False)
+    with torch.no_grad():                       # a target network that differs from the local one
+        for p in agent.qnetwork_target.parameters():
+            p.mul_(1.05)
+    s, a, r, sn, d = dqn_inputs.learn_batch(B)
+    st = torch.from_numpy(s)[:, None]
+    snt = torch.from_numpy(sn)[:, None]
+    exp = (st, torch.from_numpy(a), torch.from_numpy(r), snt, torch.from_numpy(d.astype(np.uint8)).float())
+    losses = []
+    import torch.nn.functional as F
+    real = F.mse_loss
+
+    def spy(x, y, *aa, **kw):
+        v = real(x, y, *aa, **kw)
+        losses.append(float(v))
+        return v
+    F.mse_loss = spy
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        agent.learn(exp, args.gamma)
+    F.mse_loss = real
+    out["loss"] = np.array(losses[0])
+    out["grad_sums"] = np.array([[float(p.grad.double().sum()), float(p.grad.double().abs().sum())]
+                                 for p in agent.qnetwork_local.parameters()])
+    with torch.no_grad():
+        out["q_local_after"] = agent.qnetwork_local(st).numpy()
+        out["q_target_after"] = agent.qnetwork_target(st).numpy()
+    out["local_sums"] = tensor_sums(agent.qnetwork_local)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "dqn_reference_plain.npz"), **out)
+    for k, v in out.items():
+        print(k, v.shape, v.ravel()[:4])
+
+
 if __name__ == "__main__":
-    main()
+    if "plain" in sys.argv[1:]:
+        main_plain()
+    else:
+        main()

@@ -1,7 +1,11 @@
 """Dueling Double-DQN kernels: against the reference's goldens and a plain PyTorch fp32 checker (needs an MI355X).
 
-Tolerance (stated by the task for this floating-point path): Q-values within 1e-5 relative in fp32; values
-close to zero are judged against the largest |Q| of the batch."""
+Tolerance (stated by the task for this floating-point path): Q-values within 1e-5 relative in fp32.  close_q
+applies it element by element, |got - want| <= 1e-5 * |want|, to every value above a tenth of the largest |Q| of
+the batch; values below that are sums that nearly cancel (Q = value + advantage - mean advantage) and are held
+to 1e-5 of that tenth.  The floor is where the reference's own fp32 forward pass still meets the bound against
+its float64 result (golden act_q32 vs act_q64: 9e-5 relative on a Q of 5e-4 beside 8e-2, asserted below).
+Gradients and sums use close(), relative to the tensor's scale."""
 import argparse
 import copy
 import os
@@ -20,6 +24,13 @@ def close(got, want, scale=None, rtol=RTOL):
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     scale = np.abs(want).max() if scale is None else scale
     return np.all(np.abs(got - want) <= rtol * np.maximum(np.abs(want), scale))
+
+
+def close_q(got, want, rtol=RTOL):
+    """Per-element relative agreement of Q-values with the float64 golden."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    floor = 0.1 * np.abs(want).max()
+    return bool(np.all(np.abs(got - want) <= rtol * np.maximum(np.abs(want), floor)))
 
 
 def tensor_sums(flat, shapes):
@@ -50,12 +61,14 @@ def test_forward_matches_reference_golden():
     net = net.to("cuda")
     x = torch.from_numpy(dqn_inputs.observations(6))[:, None]
     q = net(x).cpu().numpy()
-    assert close(q, gold["act_q64"])
-    assert close(q, gold["act_q32"])
+    assert close_q(q, gold["act_q64"])
+    assert close_q(gold["act_q32"], gold["act_q64"])        # the reference's own fp32 result sits inside the same band
     # one observation at a time (the act path: batch 1)
     for i in range(6):
         qi = net(x[i:i + 1]).cpu().numpy()
-        assert close(qi, gold["act_q64"][i:i + 1], scale=np.abs(gold["act_q64"]).max())
+        batch = q.copy()
+        batch[i] = qi[0]                                      # judged inside its batch: the scale is the batch's
+        assert close_q(batch, gold["act_q64"])
 
 
 def _args(B):
@@ -74,7 +87,7 @@ def test_learn_matches_reference_golden():
     agent = DQNAgent(_args(B), action_space=2, bitmap_height=H3)
     s, a, r, sn, d = dqn_inputs.learn_batch(B)
     st, snt = torch.from_numpy(s)[:, None], torch.from_numpy(sn)[:, None]
-    assert close(agent.qnetwork_local(st).cpu().numpy(), gold["learn_q_before"])
+    assert close_q(agent.qnetwork_local(st).cpu().numpy(), gold["learn_q_before"])
     exp = (st, torch.from_numpy(a), torch.from_numpy(r), snt, torch.from_numpy(d.astype(np.uint8)).float())
     agent.learn(exp, 0.99)
     shapes = [tuple(p.shape) for p in agent.qnetwork_local.parameters()]
@@ -207,11 +220,117 @@ def test_learn_from_uint8_observations_matches_float_learn():
     grads = torch.zeros((2, local.numel()), device="cuda")
     loss = torch.zeros((2, 1), device="cuda")
     ws = torch.empty(query("flm_dqn_learn_workspace_u8", B, Rp, T1), device="cuda")
-    call("flm_dqn_learn_grads", ptr(local), ptr(target), ptr(f[0]), ptr(f[1]), ptr(act), ptr(rew), ptr(done), 0.99, B,
+    call("flm_dqn_learn_grads", ptr(local), ptr(target), ptr(f[0]), ptr(f[1]), ptr(act), ptr(rew), ptr(done), 0.99, 1, B,
          3 * Rp, T1, ptr(ws), ptr(grads[0]), ptr(loss[0]), st)
     call("flm_dqn_learn_grads_u8", ptr(local), ptr(target), ptr(obs[0]), ptr(obs[1]), ps, ptr(act), ptr(rew), ptr(done),
-         0.99, B, Rp, T1, ptr(ws), ptr(grads[1]), ptr(loss[1]), st)
+         0.99, 1, B, Rp, T1, ptr(ws), ptr(grads[1]), ptr(loss[1]), st)
     torch.cuda.synchronize()
     assert torch.allclose(loss[0], loss[1], rtol=1e-5)
     scale = grads[0].abs().max().item()
     assert scale > 0 and (grads[0] - grads[1]).abs().max().item() <= 1e-5 * scale
+
+
+def test_learn_shape_of_the_benchmark_elementwise_vs_torch():
+    """The learn step at the size the training loop runs it (batch 512, max_rails 100, depth 150): loss, Q-values and
+    every gradient element through flm_dqn_learn_grads (float states) and flm_dqn_learn_grads_u8 (the replay
+    memory's bytes) against plain PyTorch fp32 on the same values."""
+    from flatland_marl_amd.agent import DQNAgent
+    from flatland_marl_amd._lib import call, ptr, query
+    from tests.torch_ref_dqn import TorchDuelingDQN, learn_step
+    B, Rp, T1 = 512, 100, 151
+    H3 = 3 * Rp
+    ps = (Rp * T1 + 255) // 256 * 256
+    args = argparse.Namespace(prediction_depth=T1 - 1, lr=5e-5, buffer_size=10, batch_size=B, update_every=1,
+                              gamma=0.99, tau=1e-3)
+    torch.manual_seed(99)
+    agent = DQNAgent(args, action_space=2, bitmap_height=H3)
+    ref_local = TorchDuelingDQN(T1, H3)
+    ref_local.load_state_dict(agent.qnetwork_local.state_dict())
+    ref_target = copy.deepcopy(ref_local)
+    with torch.no_grad():
+        for p in ref_target.parameters():
+            p.mul_(0.97)
+    agent.qnetwork_target.load_state_dict(ref_target.state_dict())
+    # observations shaped like real ones: a sparse own plane in {-1,0,1}, heat counts on the same sparse support
+    g = torch.Generator().manual_seed(5)
+    obs = torch.zeros((2, B, 3, ps), dtype=torch.uint8)
+    mask = torch.rand((2, B, Rp * T1), generator=g) < 0.02
+    own = torch.where(mask, torch.randint(0, 2, mask.shape, generator=g) * 2 - 1, torch.zeros(mask.shape, dtype=torch.long))
+    obs[:, :, 0, :Rp * T1] = own.to(torch.int8).view(torch.uint8)
+    heat = torch.rand((2, B, 2, Rp * T1), generator=g) < 0.05
+    obs[:, :, 1:, :Rp * T1] = torch.where(heat, torch.randint(1, 9, heat.shape, generator=g), torch.zeros(heat.shape, dtype=torch.long)).to(torch.uint8)
+    x = torch.cat([own.float(), obs[:, :, 1, :Rp * T1].float(), obs[:, :, 2, :Rp * T1].float()], dim=2).view(2, B, 1, H3, T1)
+    a = torch.randint(0, 2, (B,), generator=g)
+    r = -torch.rand(B, generator=g)
+    d = (torch.rand(B, generator=g) < 0.1).float()
+    opt = torch.optim.Adam(ref_local.parameters(), lr=args.lr)
+    q_ref = ref_local(x[0]).detach().numpy()
+    loss_ref = learn_step(ref_local, ref_target, opt, (x[0], a, r, x[1], d), args.gamma, args.tau).detach().numpy()
+    g_ref = [p.grad.reshape(-1).numpy() for p in ref_local.parameters()]
+    assert close_q(agent.qnetwork_local(x[0]).cpu().numpy(), q_ref)
+    assert close_q(agent.qnetwork_local.forward_obs(obs[0].cuda(), ps).cpu().numpy(), q_ref)
+    local, target = agent.qnetwork_local.flat_params(), agent.qnetwork_target.flat_params()
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(query("flm_dqn_learn_workspace_u8", B, Rp, T1), device="cuda")
+    dev = lambda t: t.cuda().contiguous()
+    da, dr, dd, dx, dobs = dev(a), dev(r), dev(d), dev(x.view(2, B, H3, T1)), dev(obs)
+    for which in ("float", "bytes"):
+        grads = torch.zeros_like(local)
+        loss = torch.zeros(1, device="cuda")
+        if which == "float":
+            call("flm_dqn_learn_grads", ptr(local), ptr(target), ptr(dx[0]), ptr(dx[1]), ptr(da), ptr(dr), ptr(dd), args.gamma,
+                 1, B, H3, T1, ptr(ws), ptr(grads), ptr(loss), st)
+        else:
+            call("flm_dqn_learn_grads_u8", ptr(local), ptr(target), ptr(dobs[0]), ptr(dobs[1]), ps, ptr(da), ptr(dr), ptr(dd),
+                 args.gamma, 1, B, Rp, T1, ptr(ws), ptr(grads), ptr(loss), st)
+        torch.cuda.synchronize()
+        assert close(loss.cpu().numpy(), loss_ref), which
+        flat, off = grads.cpu().numpy(), 0
+        for i, want in enumerate(g_ref):
+            got = flat[off:off + want.size]
+            assert close(got, want, rtol=2e-5), (which, i)
+            off += want.size
+
+
+def test_plain_dqn_matches_reference_golden():
+    """double_dqn=False: the reference's own learn step (src/agent.py:103-105, with its [B,B] broadcast of the targets
+    inside mse_loss) recorded by oracle/gen_golden_dqn.py, and the same step in plain PyTorch, element by element."""
+    from tests import dqn_inputs
+    from flatland_marl_amd.agent import DQNAgent
+    from tests.torch_ref_dqn import TorchDuelingDQN
+    import torch.nn.functional as F
+    gold = dict(np.load(os.path.join(GOLDEN, "dqn_reference_plain.npz")))
+    H3 = 3 * dqn_inputs.MAX_RAILS
+    B = 16
+    torch.manual_seed(4321)
+    agent = DQNAgent(_args(B), action_space=2, bitmap_height=H3, double_dqn=False)
+    agent.qnetwork_target.flat_params().mul_(1.05)
+    ref_local = TorchDuelingDQN(dqn_inputs.DEPTH + 1, H3)
+    ref_local.load_state_dict(agent.qnetwork_local.state_dict())
+    ref_target = TorchDuelingDQN(dqn_inputs.DEPTH + 1, H3)
+    ref_target.load_state_dict(agent.qnetwork_target.state_dict())
+    s, a, r, sn, d = dqn_inputs.learn_batch(B)
+    st, snt = torch.from_numpy(s)[:, None], torch.from_numpy(sn)[:, None]
+    at, rt, dt = torch.from_numpy(a), torch.from_numpy(r), torch.from_numpy(d.astype(np.uint8)).float()
+    agent.learn((st, at, rt, snt, dt), 0.99)
+    assert close(agent.last_loss.cpu().numpy(), gold["loss"])
+    shapes = [tuple(p.shape) for p in agent.qnetwork_local.parameters()]
+    gs = tensor_sums(agent.optimizer.grads, shapes)
+    assert close(gs[:, 1], gold["grad_sums"][:, 1], rtol=1e-5)
+    assert close_q(agent.qnetwork_local(st).cpu().numpy(), gold["q_local_after"])
+    assert close_q(agent.qnetwork_target(st).cpu().numpy(), gold["q_target_after"])
+    assert close(tensor_sums(agent.qnetwork_local.flat_params(), shapes)[:, 1], gold["local_sums"][:, 1], rtol=1e-6)
+    # the same in plain PyTorch, every gradient element
+    q = ref_local(st).gather(1, at.unsqueeze(-1)).view(B)
+    q_next = ref_target(snt).detach().max(1)[0].unsqueeze(-1)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        loss = F.mse_loss(q, rt + 0.99 * q_next * (1 - dt))
+    loss.backward()
+    assert close(agent.last_loss.cpu().numpy(), loss.detach().numpy())
+    flat, off = agent.optimizer.grads.cpu().numpy(), 0
+    for p in ref_local.parameters():
+        want = p.grad.reshape(-1).numpy()
+        assert close(flat[off:off + want.size], want, rtol=2e-5)
+        off += want.size
