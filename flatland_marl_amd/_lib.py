@@ -57,6 +57,8 @@ _SIGNATURES = {
     "flm_obs_to_f32": [_p, _i, _i, _i, _i, _p, _p],
     "flm_dqn_forward_u8": [_p, _p, _i, _i, _i, _i, _p, _p, _p],
     "flm_dqn_learn_grads": [_p, _p, _p, _p, _p, _p, _p, C.c_float, _i, _i, _i, _i, _p, _p, _p, _p],
+    "flm_replay_sample": [_i, _i, _u32, _u32, _p, _p],
+    "flm_replay_gather": [_p, _p, _p, _p, _p, _p, _i, C.c_long, _p, _p, _p, _p, _p, _p],
     "flm_dqn_adam": [_p, _p, _p, _p, C.c_long, C.c_double, C.c_double, C.c_double, C.c_double, _i, _p],
     "flm_dqn_soft_update": [_p, _p, C.c_long, C.c_double, _p],
     "flm_dqn_adam_soft_update": [_p, _p, _p, _p, _p, C.c_long, C.c_double, C.c_double, C.c_double, C.c_double, _i,

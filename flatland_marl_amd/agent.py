@@ -8,8 +8,6 @@ of the flat buffer) before the optimizer step.
 import copy
 import os
 import random
-from collections import namedtuple, deque
-from collections.abc import Iterable
 
 import numpy as np
 import torch
@@ -17,6 +15,7 @@ import torch
 from . import parallel
 from ._lib import call, ptr, query
 from .model import Dueling_DQN
+from .replay import DeviceReplay
 
 device = torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
 
@@ -169,33 +168,43 @@ class DQNAgent:
 
 
 class ReplayBuffer:
-    """Fixed-size buffer of experience tuples (host memory, uniform sampling), as in the reference."""
+    """The reference's fixed-size buffer of experience tuples with uniform sampling (src/agent.py:134-198), kept in
+    device memory: add() uploads one transition (states as float32 [height*width]), sample() draws batch_size of
+    them without replacement and returns the reference's five tensors (states and next states [B,1,height,width]
+    float, actions long, rewards and dones float) on the device."""
 
     def __init__(self, action_space, buffer_size, batch_size, width, height):
         self.action_space = action_space
-        self.memory = deque(maxlen=buffer_size)
         self.batch_size = batch_size
         self.width = width
         self.height = height
-        self.experience = namedtuple("Experience", field_names=["state", "action", "reward", "next_state", "done"])
+        self.buffer_size = buffer_size
+        self._pad = (-(height * width)) % 4                    # rows of whole 16-byte pieces
+        self._memory = None                                    # device buffers are allocated by the first add()
+
+    @property
+    def memory(self):
+        if self._memory is None:
+            self._memory = DeviceReplay(self.buffer_size, self.height * self.width + self._pad, device,
+                                        seed=random.getrandbits(32), dtype=torch.float32)
+        return self._memory
+
+    def _row(self, state):
+        x = torch.from_numpy(np.ascontiguousarray(state, dtype=np.float32).reshape(1, -1))
+        if self._pad:
+            x = torch.nn.functional.pad(x, (0, self._pad))
+        return x.to(device)
 
     def add(self, state, action, reward, next_state, done):
-        e = self.experience(np.expand_dims(state, 0), action, reward, np.expand_dims(next_state, 0), done)
-        self.memory.append(e)
+        self.memory.add(self._row(state), torch.tensor([int(action)], device=device),
+                        torch.tensor([float(reward)], device=device), self._row(next_state),
+                        torch.tensor([1.0 if done else 0.0], device=device))
 
     def sample(self):
-        experiences = random.sample(self.memory, k=self.batch_size)
-        states = torch.from_numpy(self._stack([e.state for e in experiences if e is not None])).float().to(device)
-        actions = torch.from_numpy(self._stack([e.action for e in experiences if e is not None])).long().to(device)
-        rewards = torch.from_numpy(self._stack([e.reward for e in experiences if e is not None])).float().to(device)
-        next_states = torch.from_numpy(self._stack([e.next_state for e in experiences if e is not None])).float().to(device)
-        dones = torch.from_numpy(self._stack([e.done for e in experiences if e is not None]).astype(np.uint8)).float().to(device)
-        return states, actions, rewards, next_states, dones
+        s, a, r, sn, d = self.memory.sample(self.batch_size)
+        n = self.height * self.width
+        shape = (self.batch_size, 1, self.height, self.width)
+        return s[:, :n].reshape(shape), a, r, sn[:, :n].reshape(shape), d
 
     def __len__(self):
-        return len(self.memory)
-
-    def _stack(self, items):
-        if isinstance(items[0], Iterable):
-            return np.reshape(np.array(items), (len(items), 1, self.height, self.width))
-        return np.reshape(np.array(items), (len(items)))
+        return 0 if self._memory is None else len(self._memory)

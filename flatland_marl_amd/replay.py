@@ -1,0 +1,84 @@
+"""Replay memory in device memory (the reference keeps a deque of float64 arrays on the host,
+src/agent.py:134-198): a ring of transitions, uniform sampling without replacement by flm_replay_sample, the
+sampled rows gathered into buffers that are allocated once."""
+import torch
+
+from ._lib import call, ptr
+
+
+class DeviceReplay:
+    """capacity transitions of (state row, action, reward, next-state row, done).  A row is row_shape elements of
+    `dtype`: the uint8 observation [3, plane_stride] of the batched trainer, or the float32 [H3*T1] state of the
+    drop-in agent; its size in bytes must be a multiple of 16."""
+
+    def __init__(self, capacity, row_shape, device, seed=0, dtype=torch.uint8):
+        self.capacity = int(capacity)
+        self.row_shape = tuple(int(x) for x in (row_shape if hasattr(row_shape, "__len__") else (row_shape,)))
+        self.dtype = dtype
+        n = 1
+        for x in self.row_shape:
+            n *= x
+        self.row_bytes = n * torch.empty((), dtype=dtype).element_size()
+        if self.row_bytes % 16:
+            raise ValueError("a replay row of %d bytes is not a multiple of 16" % self.row_bytes)
+        self.device = torch.device(device)
+        self.state = torch.empty((self.capacity,) + self.row_shape, dtype=dtype, device=self.device)
+        self.next_state = torch.empty((self.capacity,) + self.row_shape, dtype=dtype, device=self.device)
+        self.action = torch.zeros((self.capacity,), dtype=torch.int64, device=self.device)
+        self.reward = torch.zeros((self.capacity,), dtype=torch.float32, device=self.device)
+        self.done = torch.zeros((self.capacity,), dtype=torch.float32, device=self.device)
+        self.size = 0
+        self.head = 0
+        self.seed = int(seed) & 0xFFFFFFFF
+        self.draws = 0
+        self._out = None
+
+    def __len__(self):
+        return self.size
+
+    def add(self, state, action, reward, next_state, done):
+        """Append n transitions (oldest entries are overwritten, as with deque(maxlen))."""
+        n = state.shape[0]
+        if n > self.capacity:
+            state, action, reward, next_state, done = (x[-self.capacity:] for x in (state, action, reward, next_state, done))
+            n = self.capacity
+        # the ring is filled with at most two contiguous copies
+        first = min(n, self.capacity - self.head)
+        for dst, src in ((self.state, state), (self.next_state, next_state), (self.action, action.to(torch.int64)),
+                         (self.reward, reward.to(torch.float32)), (self.done, done.to(torch.float32))):
+            dst[self.head:self.head + first].copy_(src[:first])
+            if n > first:
+                dst[:n - first].copy_(src[first:])
+        self.head = (self.head + n) % self.capacity
+        self.size = min(self.capacity, self.size + n)
+
+    def sample_indices(self, batch_size):
+        """batch_size distinct entries, uniformly (src/agent.py:161)."""
+        if batch_size > self.size:
+            raise ValueError("Sample larger than population")       # what random.sample raises
+        idx = torch.empty((batch_size,), dtype=torch.int32, device=self.device)
+        call("flm_replay_sample", self.size, int(batch_size), self.seed, self.draws & 0xFFFFFFFF, ptr(idx),
+             torch.cuda.current_stream(self.device).cuda_stream)
+        self.draws += 1
+        return idx
+
+    def sample(self, batch_size):
+        """-> (states, actions, rewards, next_states, dones) of batch_size transitions.  The tensors are buffers of
+        this object: the next call overwrites them."""
+        B = int(batch_size)
+        if self._out is None or self._out[0].shape[0] != B:
+            dev = self.device
+            self._out = (torch.empty((B,) + self.row_shape, dtype=self.dtype, device=dev),
+                         torch.empty((B,), dtype=torch.int64, device=dev), torch.empty((B,), dtype=torch.float32, device=dev),
+                         torch.empty((B,) + self.row_shape, dtype=self.dtype, device=dev),
+                         torch.empty((B,), dtype=torch.float32, device=dev),
+                         torch.empty((B,), dtype=torch.int32, device=dev))
+        s, a, r, sn, d, idx = self._out
+        if B > self.size:
+            raise ValueError("Sample larger than population")
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        call("flm_replay_sample", self.size, B, self.seed, self.draws & 0xFFFFFFFF, ptr(idx), st)
+        self.draws += 1
+        call("flm_replay_gather", ptr(self.state), ptr(self.next_state), ptr(self.action), ptr(self.reward), ptr(self.done),
+             ptr(idx), B, self.row_bytes, ptr(s), ptr(sn), ptr(a), ptr(r), ptr(d), st)
+        return s, a, r, sn, d

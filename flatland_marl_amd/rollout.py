@@ -75,6 +75,7 @@ class RolloutBatch:
         self._dummy_i16 = torch.zeros((1,), dtype=torch.int16, device=dev)
         self.cols = None
         self._agent_flat = None
+        self._alt_pool = None
         self.t = 0
         self.malfunction = self.malfunction_moving = self.env_seed = None
         self.malf_threshold, self.malf_min, self.malf_max = 0, 0, 0
@@ -152,11 +153,23 @@ class RolloutBatch:
         n, K, dev = req.numel(), self.cap_alt, self.device
         i32 = dict(dtype=torch.int32, device=dev)
         n_ready = 0 if ready is None else ready.numel()
-        alt = dict(count=torch.empty((n,), **i32), len=torch.zeros((n, K), **i32),
-                   cell=torch.empty((n, K, self.Lp), **i32), meta=torch.empty((n, K, self.Lp), **i32),
-                   err=torch.empty((n,), **i32), cols=torch.empty((n, K, b.T1), dtype=torch.int16, device=dev),
-                   col_err=torch.empty((n, K), **i32), req=req, row_offset=torch.empty((n + 1,), **i32),
-                   row_req=torch.empty((n_ready + n * K,), **i32), row_own=torch.empty((n_ready + n * K,), **i32))
+        # the tables live in buffers that only ever grow: a step allocates nothing once they have reached the
+        # largest number of agents in front of a switch seen so far
+        pool = self._alt_pool
+        if pool is None or pool["cap"] < n or pool["cap_rows"] < n_ready + n * K:
+            cap = max(n, 64, 0 if pool is None else pool["cap"] * 3 // 2)
+            cap_rows = max(n_ready + n * K, self.E * self.A + cap * K)
+            pool = self._alt_pool = dict(
+                cap=cap, cap_rows=cap_rows, count=torch.empty((cap,), **i32), len=torch.zeros((cap, K), **i32),
+                cell=torch.empty((cap, K, self.Lp), **i32), meta=torch.empty((cap, K, self.Lp), **i32),
+                err=torch.empty((cap,), **i32), cols=torch.empty((cap, K, b.T1), dtype=torch.int16, device=dev),
+                col_err=torch.empty((cap, K), **i32), row_offset=torch.empty((cap + 1,), **i32),
+                row_req=torch.empty((cap_rows,), **i32), row_own=torch.empty((cap_rows,), **i32))
+        alt = dict(count=pool["count"][:n], len=pool["len"][:n], cell=pool["cell"][:n], meta=pool["meta"][:n],
+                   err=pool["err"][:n], cols=pool["cols"][:n], col_err=pool["col_err"][:n], req=req,
+                   row_offset=pool["row_offset"][:n + 1], row_req=pool["row_req"][:n_ready + n * K],
+                   row_own=pool["row_own"][:n_ready + n * K])
+        alt["len"].zero_()
         for lo in range(0, n, MAX_REQ):
             hi = min(n, lo + MAX_REQ)
             call("flm_altpaths", ptr(b.grid), ptr(b.cell_idx), ptr(b.dist), ptr(b.succ_table()), ptr(b.choice_table()),
@@ -232,8 +245,9 @@ class RolloutBatch:
         b = self.b
         self.classify()
         # the consulting agents (ordered lists), cleared decisions, and the batch's view of the agents
-        self._net = torch.empty((self.E, self.A), dtype=torch.int32, device=self.device)
-        self._best = torch.empty((self.E, self.A), dtype=torch.int32, device=self.device)
+        if getattr(self, "_net", None) is None:
+            self._net = torch.empty((self.E, self.A), dtype=torch.int32, device=self.device)
+            self._best = torch.empty((self.E, self.A), dtype=torch.int32, device=self.device)
         call("flm_rollout_requests", ptr(self.branch), ptr(self.status), ptr(self.pos), ptr(self.heading),
              ptr(b.start_cell), self.E, self.A, ptr(self.ready_list), ptr(self.switch_list), ptr(self.req_counts),
              ptr(self.alt_slot), ptr(self._net), ptr(self._best), ptr(b.pos_cell), ptr(b.direction), ptr(b.status),

@@ -23,6 +23,7 @@ import torch
 
 from . import parallel
 from ._lib import call, ptr
+from .replay import DeviceReplay
 from .rollout import RolloutBatch
 
 
@@ -99,44 +100,6 @@ class DQNPolicy:
         return self._last
 
 
-class DeviceReplay:
-    def __init__(self, capacity, plane_stride, device, seed=0):
-        self.capacity = int(capacity)
-        self.ps = plane_stride
-        self.state = torch.empty((self.capacity, 3, plane_stride), dtype=torch.uint8, device=device)
-        self.next_state = torch.empty((self.capacity, 3, plane_stride), dtype=torch.uint8, device=device)
-        self.action = torch.zeros((self.capacity,), dtype=torch.int64, device=device)
-        self.reward = torch.zeros((self.capacity,), dtype=torch.float32, device=device)
-        self.done = torch.zeros((self.capacity,), dtype=torch.float32, device=device)
-        self.size = 0
-        self.head = 0
-        self.gen = torch.Generator(device=device)
-        self.gen.manual_seed(seed)
-
-    def __len__(self):
-        return self.size
-
-    def add(self, state, action, reward, next_state, done):
-        """Append n transitions (oldest entries are overwritten, as with deque(maxlen))."""
-        n = state.shape[0]
-        if n > self.capacity:
-            state, action, reward, next_state, done = (x[-self.capacity:] for x in (state, action, reward, next_state, done))
-            n = self.capacity
-        # the ring is filled with at most two contiguous copies
-        first = min(n, self.capacity - self.head)
-        for dst, src in ((self.state, state), (self.next_state, next_state), (self.action, action.to(torch.int64)),
-                         (self.reward, reward.to(torch.float32)), (self.done, done.to(torch.float32))):
-            dst[self.head:self.head + first].copy_(src[:first])
-            if n > first:
-                dst[:n - first].copy_(src[first:])
-        self.head = (self.head + n) % self.capacity
-        self.size = min(self.capacity, self.size + n)
-
-    def sample(self, batch_size):
-        idx = torch.randperm(self.size, generator=self.gen, device=self.state.device)[:batch_size]
-        return self.state[idx], self.action[idx], self.reward[idx], self.next_state[idx], self.done[idx]
-
-
 class BatchedTrainer:
     def __init__(self, rollout: RolloutBatch, agent, replay_capacity=None, max_steps=200, start_eps=1.0, end_eps=0.005,
                  eps_decay=0.998, crash_penalty=False, switch2switch=False, max_learns_per_step=None, seed=0,
@@ -148,7 +111,7 @@ class BatchedTrainer:
             raise ValueError("the network expects %dx%d inputs, the batch produces %dx%d"
                              % (agent.height, agent.width, 3 * b.Rp, b.T1))
         cap = replay_capacity or agent.args.buffer_size
-        self.replay = DeviceReplay(cap, b.plane_stride, rollout.device, seed=seed + 1)
+        self.replay = DeviceReplay(cap, (3, b.plane_stride), rollout.device, seed=seed + 1)
         self.policy = DQNPolicy(agent, eps=start_eps, seed=seed)
         self.max_steps = max_steps
         self.eps, self.end_eps, self.eps_decay = start_eps, end_eps, eps_decay

@@ -410,6 +410,19 @@ int flm_dqn_learn_grads_u8(const float* local, const float* target, const uint8_
                            int double_dqn, int B, int Rp, int T1, float* workspace, float* grads, float* loss_out,
                            void* stream);
 
+/* Uniform sampling without replacement from a replay memory that lives in device memory, and the gather of the
+ * sampled transitions.  Replaces ReplayBuffer.sample, src/agent.py:159-174 (random.sample over the deque, then
+ * one stacked tensor per field).
+ *   flm_replay_sample  idx [batch] int32 out: `batch` distinct entries of 0..size-1, every subset equally likely
+ *                      (the entries with the smallest keys hash(seed, draw, entry), listed in index order;
+ *                      give every call its own `draw`).  batch <= size.
+ *   flm_replay_gather  rows idx[b] of state / next_state (row_bytes bytes each, a multiple of 16, 16-byte aligned
+ *                      bases) and of action int64 / reward float / done float -> the out_* arrays, row b. */
+int flm_replay_sample(int size, int batch, uint32_t seed, uint32_t draw, int32_t* idx, void* stream);
+int flm_replay_gather(const void* state, const void* next_state, const int64_t* action, const float* reward,
+                      const float* done, const int32_t* idx, int batch, long row_bytes, void* out_state, void* out_next,
+                      int64_t* out_action, float* out_reward, float* out_done, void* stream);
+
 /* torch.optim.Adam step with default options over flat buffers (src/agent.py:38,113-115); step counts from 1. */
 int flm_dqn_adam(float* params, const float* grads, float* m, float* v, long n, double lr, double beta1, double beta2,
                  double eps, int step, void* stream);

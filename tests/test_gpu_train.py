@@ -200,3 +200,89 @@ def test_policy_select_kernel():
     assert (best[sw] >= 0).all() and (best[sw][has] < cnt[has]).all() and (best[sw][~has] == 0).all()
     assert len(np.unique(best[sw[cnt == 4]])) == 4             # every alternative gets drawn
     assert 0.3 < net[ready].mean() < 0.7
+
+
+def test_replay_sampling_kernel():
+    """flm_replay_sample: distinct entries, the same for the same (seed, draw), every entry about equally often;
+    flm_replay_gather: the rows those entries name."""
+    import torch
+    from flatland_marl_amd.replay import DeviceReplay
+    dev = "cuda"
+    rp = DeviceReplay(5000, (3, 48), dev, seed=11)
+    g = torch.Generator().manual_seed(0)
+    n = 3210
+    state = torch.randint(0, 255, (n, 3, 48), generator=g).to(torch.uint8)
+    nxt = torch.randint(0, 255, (n, 3, 48), generator=g).to(torch.uint8)
+    act = torch.randint(0, 2, (n,), generator=g)
+    rew = torch.randn(n, generator=g)
+    done = (torch.rand(n, generator=g) < 0.3).float()
+    rp.add(state.cuda(), act.cuda(), rew.cuda(), nxt.cuda(), done.cuda())
+    assert len(rp) == n
+    counts = np.zeros(n, np.int64)
+    B, draws = 512, 300
+    seen = set()
+    for k in range(draws):
+        idx = rp.sample_indices(B).cpu().numpy()
+        assert len(np.unique(idx)) == B and idx.min() >= 0 and idx.max() < n            # without replacement
+        assert np.all(np.diff(idx) > 0)                                                  # listed in index order
+        counts[idx] += 1
+        seen.add(idx.tobytes())
+    assert len(seen) == draws                                                            # every draw differs
+    # every entry is drawn with probability B/n: binomial(draws, B/n), far tails excluded
+    p = B / n
+    mean, sd = draws * p, (draws * p * (1 - p)) ** 0.5
+    assert abs(counts.mean() - mean) < 1e-9 and counts.min() > mean - 6 * sd and counts.max() < mean + 6 * sd
+    assert abs(counts[: n // 2].mean() - counts[n // 2:].mean()) < 0.5                   # no drift along the memory
+    # the same seed and draw number give the same sample; another seed another one
+    a = DeviceReplay(5000, (3, 48), dev, seed=11)
+    b = DeviceReplay(5000, (3, 48), dev, seed=12)
+    for r_ in (a, b):
+        r_.add(state.cuda(), act.cuda(), rew.cuda(), nxt.cuda(), done.cuda())
+    rp.draws = 0
+    i0, ia, ib = rp.sample_indices(B), a.sample_indices(B), b.sample_indices(B)
+    assert torch.equal(i0, ia) and not torch.equal(i0, ib)
+    # gather
+    rp.draws = 7
+    idx = rp.sample_indices(B).cpu().long()
+    rp.draws = 7
+    s, ac, rw, sn, dn = rp.sample(B)
+    assert torch.equal(s.cpu(), state[idx]) and torch.equal(sn.cpu(), nxt[idx]) and torch.equal(ac.cpu(), act[idx])
+    assert torch.equal(rw.cpu(), rew[idx]) and torch.equal(dn.cpu(), done[idx])
+    # the whole memory can be asked for; more than it holds cannot
+    assert sorted(rp.sample_indices(n).cpu().tolist()) == list(range(n))
+    with pytest.raises(ValueError):
+        rp.sample_indices(n + 1)
+    # ring: the oldest entries are overwritten
+    rp.add(state[:2000].cuda(), act[:2000].cuda(), rew[:2000].cuda(), nxt[:2000].cuda(), done[:2000].cuda())
+    assert len(rp) == 5000 and rp.head == (n + 2000) % 5000
+    assert torch.equal(rp.state[n:5000].cpu(), state[:5000 - n]) and torch.equal(rp.state[:rp.head].cpu(), state[5000 - n:2000])
+
+
+def test_drop_in_replay_buffer_keeps_the_reference_interface():
+    """ReplayBuffer(action_space, buffer_size, batch_size, width, height): add / sample / len as src/agent.py:134-198,
+    tensors of the reference's shapes and types, sampled transitions are stored ones."""
+    import torch
+    from flatland_marl_amd.agent import ReplayBuffer
+    H, W = 9, 7                                               # 63 values per state: rows are padded to 16 bytes inside
+    buf = ReplayBuffer(2, 50, 8, W, H)
+    assert len(buf) == 0
+    rng = np.random.default_rng(0)
+    items = []
+    for k in range(70):
+        s, sn = rng.integers(-1, 5, (H, W)).astype(np.float64), rng.integers(-1, 5, (H, W)).astype(np.float64)
+        items.append((s, k % 2, -0.25 * (k % 4), sn, k % 5 == 0))
+        buf.add(*items[-1])
+    assert len(buf) == 50                                     # the 20 oldest are gone
+    states, actions, rewards, next_states, dones = buf.sample()
+    assert states.shape == (8, 1, H, W) and next_states.shape == (8, 1, H, W) and states.dtype == torch.float32
+    assert actions.dtype == torch.int64 and rewards.dtype == torch.float32 and dones.dtype == torch.float32
+    assert states.is_cuda
+    kept = {(x[0].astype(np.float32).tobytes(), x[1], np.float32(x[2]).item(), x[3].astype(np.float32).tobytes(), float(x[4]))
+            for x in items[20:]}
+    got = set()
+    for i in range(8):
+        t = (states[i, 0].cpu().numpy().tobytes(), int(actions[i]), float(rewards[i]), next_states[i, 0].cpu().numpy().tobytes(),
+             float(dones[i]))
+        assert t in kept
+        got.add(t)
+    assert len(got) == 8
