@@ -317,6 +317,81 @@ __global__ __launch_bounds__(256) void fc1_small_kernel(const float* __restrict_
   }
 }
 
+// ---- small-batch first dense layer, both streams in one launch ---------------------------------------------
+// The layer is bound by streaming its weights (2 x 512 x K floats: 78.6 MB at max_rails 100) once.  A workgroup
+// of 16 waves owns four output neurons; its 1024 threads take the 16-byte pieces of the four weight rows
+// round-robin (every load of a wave is 1 KiB of one row), so a lane has its x pieces in registers and about
+// twenty independent weight loads in flight; 256 workgroups cover the 1024 neurons of the two streams, one per
+// CU.  Lanes reduce inside the wave, the sixteen waves meet in LDS and are summed in a fixed order.
+template <int BMAX>
+__global__ __launch_bounds__(1024) void fc1_rows_kernel(const float* __restrict__ X, const float* __restrict__ Wadv,
+                                                        const float* __restrict__ Wval, const float* __restrict__ badv,
+                                                        const float* __restrict__ bval, int B, long K, float* __restrict__ out) {
+  constexpr int R = 4;
+  __shared__ float part[16][R][BMAX];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int row0 = blockIdx.x * R;                       // 0..1023: advantage stream first, then the value stream
+  const float* W = row0 < 512 ? Wadv + (long)row0 * K : Wval + (long)(row0 - 512) * K;
+  const long K4 = K >> 2;
+  float acc[R][BMAX];
+#pragma unroll
+  for (int r = 0; r < R; r++)
+#pragma unroll
+    for (int b = 0; b < BMAX; b++) acc[r][b] = 0.f;
+  for (long i0 = tid; i0 < K4; i0 += 4 * 1024) {         // four pieces of every row per trip
+    float4 w[4][R], x[4][BMAX];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const long i = i0 + (long)u * 1024;
+      const bool in = i < K4;
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        if (in) {
+          typedef float v4f __attribute__((ext_vector_type(4)));
+          const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(W + (long)r * K) + i);   // read once
+          w[u][r] = make_float4(t.x, t.y, t.z, t.w);
+        } else {
+          w[u][r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+      for (int b = 0; b < BMAX; b++)
+        x[u][b] = (in && b < B) ? reinterpret_cast<const float4*>(X + (long)b * K)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int b = 0; b < BMAX; b++) {
+          acc[r][b] = fmaf(w[u][r].x, x[u][b].x, acc[r][b]);
+          acc[r][b] = fmaf(w[u][r].y, x[u][b].y, acc[r][b]);
+          acc[r][b] = fmaf(w[u][r].z, x[u][b].z, acc[r][b]);
+          acc[r][b] = fmaf(w[u][r].w, x[u][b].w, acc[r][b]);
+        }
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++)
+#pragma unroll
+    for (int b = 0; b < BMAX; b++) {
+      float v = acc[r][b];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+      if (lane == 0) part[wave][r][b] = v;
+    }
+  __syncthreads();
+  if (tid < R * BMAX) {
+    const int r = tid / BMAX, b = tid - r * BMAX;
+    if (b < B) {
+      float v = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < 16; w2++) v += part[w2][r][b];
+      const int row = row0 + r;
+      v += row < 512 ? badv[row] : bval[row - 512];
+      out[(long)b * 1024 + row] = v > 0.f ? v : 0.f;
+    }
+  }
+}
+
 // ---- output layers + dueling combination, one wave per sample ------------------------------------------
 // hid[B,1024]: columns 0..511 advantage stream, 512..1023 value stream.  q[B,2].
 __global__ __launch_bounds__(64) void head_forward_kernel(const float* __restrict__ hid, const float* __restrict__ a2w,
@@ -816,7 +891,18 @@ static int dqn_forward_impl(const float* params, const float* x, const uint8_t* 
       rc = FLM_E_ARG;
     if (rc) return rc;
   }
-  if (B <= 8 && (L.K1 & 3) == 0) {
+  if (B <= 8 && (L.K1 & 3) == 0 && (((uintptr_t)(params + L.a1_w) | (uintptr_t)(params + L.v1_w) | (uintptr_t)x1) & 15) == 0) {
+    if (B == 1)
+      hipLaunchKernelGGL(flm::fc1_rows_kernel<1>, dim3(256), dim3(1024), 0, stream, x1, params + L.a1_w, params + L.v1_w,
+                         params + L.a1_b, params + L.v1_b, B, L.K1, hid);
+    else if (B <= 4)
+      hipLaunchKernelGGL(flm::fc1_rows_kernel<4>, dim3(256), dim3(1024), 0, stream, x1, params + L.a1_w, params + L.v1_w,
+                         params + L.a1_b, params + L.v1_b, B, L.K1, hid);
+    else
+      hipLaunchKernelGGL(flm::fc1_rows_kernel<8>, dim3(256), dim3(1024), 0, stream, x1, params + L.a1_w, params + L.v1_w,
+                         params + L.a1_b, params + L.v1_b, B, L.K1, hid);
+    if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
+  } else if (B <= 8 && (L.K1 & 3) == 0) {
     hipLaunchKernelGGL(flm::fc1_small_kernel<8>, dim3(128), dim3(256), 0, stream, x1, params + L.a1_w, params + L.a1_b, B,
                        L.K1, hid, 1024, 512);
     hipLaunchKernelGGL(flm::fc1_small_kernel<8>, dim3(128), dim3(256), 0, stream, x1, params + L.v1_w, params + L.v1_b, B,
