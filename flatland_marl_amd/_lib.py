@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libflmarl_hip.so")
+# FLMARL_LIB names another build of the same library (experiments); the default is the in-tree one
+LIB_PATH = os.environ.get("FLMARL_LIB") or os.path.join(_HERE, "libflmarl_hip.so")
 
 FLM_OK = 0
 AGENT_ERRORS = {2: IndexError, 3: KeyError, 4: AssertionError, 5: OverflowError}
@@ -25,7 +26,7 @@ _SIGNATURES = {
     "flm_state_index": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     "flm_distance_bfs": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p],
     "flm_target_slots": [_p, _i, _i, _p, _p, _p, _p],
-    "flm_chain_index": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "flm_chain_index": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "flm_paths_columns_lds_bytes": [_i, _i, _i, _i, _i, _i, _i],
     "flm_paths_columns_workspace": [_i, _i, _i, _i],
     "flm_paths_columns": [_p] * 22 + [_i] * 14 + [_p] * 8,

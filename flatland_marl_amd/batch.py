@@ -215,7 +215,7 @@ class ObservationBatch:
         call("flm_chain_index", ptr(self.grid), ptr(self.cell_idx), ptr(self.n_cells), ptr(self.target_cell), E, A,
              self.H, self.W, self.cap_cells, self.cap_anchor, ptr(self.chain_root), ptr(self.chain_steps),
              ptr(self.chain_edges), ptr(self.n_anchor), ptr(self.counts), ptr(self.chain_succ), ptr(self.chain_choice),
-             ptr(self.chain_walk), ptr(self.move_edge), ptr(self.move_succ), s)
+             ptr(self.chain_walk), ptr(self.move_edge), ptr(self.move_succ), ptr(self.idx_cell), s)
         self._succ_valid = True
         if getattr(self, "lds_anchor", None) is None:
             # anchors = states with a choice of moves (fixed by the grid) + states on target cells (<= 4*A).

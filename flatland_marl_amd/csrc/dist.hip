@@ -27,7 +27,7 @@ __global__ __launch_bounds__(1024, 8) void chain_index_kernel(
     int capAnch, uint16_t* __restrict__ root_all, uint16_t* __restrict__ steps_all, uint32_t* __restrict__ edges_all,
     int32_t* __restrict__ n_anchor_all, int32_t* __restrict__ counts_all, uint16_t* __restrict__ succ_all,
     uint16_t* __restrict__ choice_all, uint16_t* __restrict__ walk_all, uint32_t* __restrict__ move_edge_all,
-    uint16_t* __restrict__ move_succ_all) {
+    uint16_t* __restrict__ move_succ_all, const int32_t* __restrict__ idx_cell_all) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int e = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
   const int HW = H * W;
@@ -35,6 +35,10 @@ __global__ __launch_bounds__(1024, 8) void chain_index_kernel(
   const int S = n_cells_all[e] * 4;
   const uint16_t* grid = grid_all + (size_t)e * HW;
   const int32_t* cell_idx = cell_idx_all + (size_t)e * HW;
+  // the rail cells are visited through the compact numbering's inverse table when the caller has one (a fraction
+  // of the H*W grid cells), otherwise by scanning the grid
+  const int32_t* idx_cell = idx_cell_all ? idx_cell_all + (size_t)e * capCells : nullptr;
+  const int n_visit = idx_cell ? S / 4 : HW;
   uint16_t* jmp0 = reinterpret_cast<uint16_t*>(smem);   // [capS]
   uint16_t* jmp1 = jmp0 + capS;
   uint16_t* stp0 = jmp1 + capS;
@@ -58,8 +62,9 @@ __global__ __launch_bounds__(1024, 8) void chain_index_kernel(
   }
   __syncthreads();
   // classify every state; successor of single-move states
-  for (int cell = tid; cell < HW; cell += T) {
-    const int ci = cell_idx[cell];
+  for (int it = tid; it < n_visit; it += T) {
+    const int cell = idx_cell ? idx_cell[it] : it;
+    const int ci = idx_cell ? it : cell_idx[cell];
     if (ci < 0) continue;
     const int r = cell / W, c = cell - r * W;
     const unsigned code = grid[cell];
@@ -126,16 +131,22 @@ __global__ __launch_bounds__(1024, 8) void chain_index_kernel(
   }
   // pointer doubling
   uint16_t* ja = jmp0; uint16_t* jb = jmp1; uint16_t* sa = stp0; uint16_t* sb = stp1;
+  // (a round in which every pointer already names a fixed point changes nothing: the loop ends there, after
+  // about log2 of the longest run of forced moves; only anchor-free loops keep it going to log2 S)
   for (int span = 1; span < S; span <<= 1) {
+    int more = 0;
     for (int s = tid; s < S; s += T) {
       const int j = ja[s];
+      const int jj = ja[j];
       unsigned st = (unsigned)sa[s] + (unsigned)sa[j];
-      jb[s] = ja[j];
+      more |= jj != j;
+      jb[s] = (uint16_t)jj;
       sb[s] = (uint16_t)(st > 0xFFFEu ? 0xFFFEu : st);
     }
-    __syncthreads();
+    more = __syncthreads_or(more);
     uint16_t* t = ja; ja = jb; jb = t;
     t = sa; sa = sb; sb = t;
+    if (!more) break;
   }
   // number the anchors in state order
   int n_anchor = 0;
@@ -181,8 +192,9 @@ __global__ __launch_bounds__(1024, 8) void chain_index_kernel(
     }
   }
   // per anchor: one edge per move
-  for (int cell = tid; cell < HW; cell += T) {
-    const int ci = cell_idx[cell];
+  for (int it = tid; it < n_visit; it += T) {
+    const int cell = idx_cell ? idx_cell[it] : it;
+    const int ci = idx_cell ? it : cell_idx[cell];
     if (ci < 0) continue;
     const int r = cell / W, c = cell - r * W;
     const unsigned code = grid[cell];
@@ -340,7 +352,7 @@ extern "C" int flm_chain_index(const uint16_t* grid, const int32_t* cell_idx, co
                                const int32_t* target_cell, int E, int A, int H, int W, int capCells, int capAnch,
                                uint16_t* root, uint16_t* steps, uint32_t* edges, int32_t* n_anchor, int32_t* counts,
                                uint16_t* succ, uint16_t* choice, uint16_t* walk, uint32_t* move_edge, uint16_t* move_succ,
-                               void* stream) {
+                               const int32_t* idx_cell, void* stream) {
   if (!grid || !cell_idx || !n_cells || !target_cell || !root || !steps || !edges || !n_anchor || !counts) return FLM_E_ARG;
   if ((walk || move_edge || move_succ) && !(walk && move_edge && move_succ && succ)) return FLM_E_ARG;   // all or none
   if (walk && capCells * 4 > 32768) return FLM_E_ARG;   // bit 15 of a walk entry marks an anchor
@@ -354,7 +366,7 @@ extern "C" int flm_chain_index(const uint16_t* grid, const int32_t* cell_idx, co
     return FLM_E_LAUNCH;
   hipLaunchKernelGGL(flm::chain_index_kernel, dim3(E), dim3(1024), lds, (hipStream_t)stream, grid, cell_idx, n_cells,
                      target_cell, A, H, W, capCells, capAnch, root, steps, edges, n_anchor, counts, succ, choice, walk,
-                     move_edge, move_succ);
+                     move_edge, move_succ, idx_cell);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }

@@ -116,6 +116,9 @@ int flm_distance_bfs(const uint16_t* pred, const int32_t* cell_idx, const int32_
  *                      as forward; move_succ = the states those moves lead to, fourth entry the same flag.
  *                      Anchors are the states with two or more moves, the states on target cells, and the
  *                      states with one move that a walk does not treat as forced;
+ *                      idx_cell [E,capCells] int32 (may be NULL): the inverse of cell_idx as written by
+ *                      flm_state_index; with it the kernel visits the rail cells directly instead of scanning
+ *                      the H*W grid (same tables);
  *   flm_distance_chains  dist [E,A,capCells*4] as flm_distance_bfs; ldsAnch <= capAnch is the number of
  *                      anchors the workgroup's LDS tables are sized for (80 bytes each); an environment
  *                      with more anchors is flagged in counts[e*4+3] and its rows are left unwritten. */
@@ -124,7 +127,7 @@ int flm_target_slots(const int32_t* target_cell, int E, int A, int32_t* tslot, i
 int flm_chain_index(const uint16_t* grid, const int32_t* cell_idx, const int32_t* n_cells, const int32_t* target_cell,
                     int E, int A, int H, int W, int capCells, int capAnch, uint16_t* root, uint16_t* steps,
                     uint32_t* edges, int32_t* n_anchor, int32_t* counts, uint16_t* succ, uint16_t* choice,
-                    uint16_t* walk, uint32_t* move_edge, uint16_t* move_succ, void* stream);
+                    uint16_t* walk, uint32_t* move_edge, uint16_t* move_succ, const int32_t* idx_cell, void* stream);
 int flm_distance_chains(const uint16_t* root, const uint16_t* steps, const uint32_t* edges, const int32_t* n_anchor,
                         const int32_t* n_cells, const int32_t* cell_idx, const int32_t* slot_target,
                         const int32_t* n_slots, int E, int A, int H, int W, int capCells, int capAnch, int ldsAnch,
