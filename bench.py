@@ -32,6 +32,10 @@ WORKLOADS = {
              "256 envs x 200 agents, 150x150 grid (Test_9-class maps), depth 300"),
     "cfg2": (["Test_2_Level_0", "Test_2_Level_1"], 1024, 10, 150,
              "1024 envs x 10 agents, 35x35 grid (Test_2-class maps stand in for 25x25), max_rails 70+, depth 150"),
+    # the headline shape on 256 distinct generated 100x100 grids (about 580 rails each), so that the graph, chain and
+    # distance kernels do not see the same few grids over and over
+    "cfg3g": (dict(H=100, W=100, n_maps=256, spacing=5, keep=0.85, symmetries=False, scc_targets=True), 4096, 50, 150,
+              "4096 envs x 50 agents, 256 distinct generated 100x100 grids (about 580 rails), agents re-drawn, depth 150"),
     # the same shape on grids from the package's own generator (flatland's generator is not available)
     "cfg2g": (dict(H=25, W=25, n_maps=8, spacing=4, max_rails=70), 1024, 10, 150,
               "1024 envs x 10 agents, generated 25x25 grids (8 grids x 8 symmetries), max_rails 70, depth 150"),
@@ -155,6 +159,23 @@ def guarded_rollout_sample(out, rank, timeout_s, **kw):
     return res
 
 
+def masked_stream(device, n_cu, bits):
+    """A HIP stream whose kernels only run on the compute units named in `bits` (hipExtStreamCreateWithCUMask),
+    wrapped for torch."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    n_words = (n_cu + 31) // 32
+    words = (ctypes.c_uint32 * n_words)()
+    for b in bits:
+        words[b >> 5] |= 1 << (b & 31)
+    st = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(n_words), words)
+    if rc != 0 or not st.value:
+        raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
+    return torch.cuda.ExternalStream(st.value, device=device)
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -219,6 +240,11 @@ def main():
     ap.add_argument("--obs-serial", type=int, default=1,
                     help="1: observation kernels run one after the other on the main stream after the other stages; "
                          "2: pipelined, the other stages of the next sub-batch run on a side stream meanwhile")
+    ap.add_argument("--front-cus", type=int, default=0,
+                    help="with --obs-serial 2: the side stream (graph .. columns) may only use this many compute units, "
+                         "the observation sweep the others (0: no masks)")
+    ap.add_argument("--cu-pattern", default="spread", choices=["spread", "low"],
+                    help="which bits of the compute-unit mask the side stream gets: every k-th bit, or the lowest ones")
     ap.add_argument("--paths", default="fused", choices=["fused", "dense"],
                     help="fused: paths and columns straight from the chain index (default when the tables fit the LDS); "
                          "dense: distance maps -> shortest paths -> columns as separate kernels")
@@ -259,6 +285,17 @@ def main():
     streams = [torch.cuda.Stream(device=device) for _ in range(max(1, args.streams))] if args.streams > 1 or n_chunks > 1 \
         else [torch.cuda.current_stream(device)]
     main_stream = torch.cuda.current_stream(device)
+    side_stream = streams[0]
+    if args.front_cus > 0 and args.obs_serial == 2:
+        n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+        k = max(1, min(args.front_cus, n_cu - 1))
+        if args.cu_pattern == "low":
+            front_bits = set(range(k))
+        else:
+            front_bits = set(int(i * n_cu / k) for i in range(k))
+        side_stream = masked_stream(device, n_cu, front_bits)
+        main_stream = masked_stream(device, n_cu, set(range(n_cu)) - front_bits)
+        torch.cuda.set_stream(main_stream)
     batches = []
     for ci in range(n_chunks):
         lo, hi = parallel.shard_range(E, ci, n_chunks)
@@ -298,7 +335,7 @@ def main():
 
     def step_pipelined(ev=None):
         # side stream: graph .. columns of sub-batch i+1 while the main stream writes the observations of sub-batch i
-        side = streams[0]
+        side = side_stream
         for ci, b in enumerate(batches):
             keep, b.stream = b.stream, side
             with torch.cuda.stream(side):

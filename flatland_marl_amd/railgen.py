@@ -248,6 +248,50 @@ def draw_agents(grid, A, rng, graph=None, allow_same_track=False, depth=150):
     return start, heading, target, SPEEDS[rng.integers(4, size=A)]
 
 
+def draw_agents_scc(grid, A, rng, graph, depth=150):
+    """draw_agents for large batches: instead of one breadth-first search per agent, the strongly connected
+    components of the state graph are computed once per grid, and a target is drawn among the straight cells that
+    have a state in the start state's component (every state of a component reaches every other one, so the
+    target is reachable; targets outside the component are never drawn).  Same exclusions as draw_agents
+    without allow_same_track."""
+    from scipy.sparse.csgraph import connected_components
+    H, W = grid.shape
+    cache = getattr(graph, "_scc", None)
+    if cache is None:
+        st = stations(grid)
+        comp = connected_components(graph.csr, directed=True, connection="strong")[1]
+        is_station = np.zeros(grid.shape, bool)
+        for (r, c), _ in st:
+            is_station[r, c] = True
+        ok_start = [i for i, (cell, h) in enumerate(st) if graph.cells_to_first_switch(cell, h, depth) <= depth // 4 - 2]
+        cache = graph._scc = dict(st=st, comp=comp.reshape(H, W, 4), is_station=is_station, ok_start=ok_start, cand={})
+    st, comp, cand = cache["st"], cache["comp"], cache["cand"]
+    if not cache["ok_start"]:
+        raise ValueError("no start that sees a switch within the prediction depth")
+    start = np.empty((A, 2), np.int32)
+    heading = np.empty((A,), np.int32)
+    target = np.empty((A, 2), np.int32)
+    order = rng.permutation(len(cache["ok_start"]))
+    k = 0
+    for a in range(A):
+        for _ in range(4 * len(order)):
+            cell, h = st[cache["ok_start"][order[k % len(order)]]]
+            k += 1
+            label = int(comp[cell[0], cell[1], h])
+            if label not in cand:
+                cand[label] = (comp == label).any(axis=2) & cache["is_station"]
+            ok = cand[label] & (graph.track != graph.track[cell[0], cell[1]])
+            ok[cell[0], cell[1]] = False
+            cells = np.argwhere(ok)
+            if len(cells):
+                break
+        else:
+            raise ValueError("no start with a reachable target")
+        start[a], heading[a] = cell, h
+        target[a] = cells[rng.integers(len(cells))]
+    return start, heading, target, SPEEDS[rng.integers(4, size=A)]
+
+
 def generate_env(H, W, A, seed=0, allow_same_track=False, depth=150, **rail_kw):
     """One environment in the layout of the stored fixtures: dict(grid, initial_position, initial_direction,
     direction, target, speed, handle, status)."""
@@ -264,11 +308,12 @@ def generate_env(H, W, A, seed=0, allow_same_track=False, depth=150, **rail_kw):
                 speed=speed, handle=np.arange(A, dtype=np.int32), status=np.zeros(A, np.int32))
 
 
-def make_generated_batch(E, A, H, W, seed=0, n_maps=8, depth=150, **rail_kw):
+def make_generated_batch(E, A, H, W, seed=0, n_maps=8, depth=150, symmetries=True, scc_targets=False, **rail_kw):
     """E environments of A agents on generated H x W grids: n_maps distinct grids, each used under the
-    symmetries of the grid shape, agents re-drawn per environment.  Same layout as synthetic.make_batch."""
+    symmetries of the grid shape (symmetries=False: as generated only), agents re-drawn per environment.
+    scc_targets draws the agents with draw_agents_scc (large batches).  Same layout as synthetic.make_batch."""
     maps = [generate_env(H, W, 1, seed=seed * 1000 + m, **rail_kw)["grid"] for m in range(n_maps)]
-    syms = range(8) if H == W else [0, 1, 4, 5]
+    syms = [0] if not symmetries else (range(8) if H == W else [0, 1, 4, 5])
     variants = [transform(g, [], [], s)[0] for g in maps for s in syms]
     graphs = [_StateGraph(g) for g in variants]
     out = dict(grid=np.empty((E, H, W), np.uint16), start=np.empty((E, A, 2), np.int32),
@@ -278,6 +323,10 @@ def make_generated_batch(E, A, H, W, seed=0, n_maps=8, depth=150, **rail_kw):
         g = variants[e % len(variants)]
         rng = np.random.default_rng(seed + 7919 * (e + 1))
         out["grid"][e] = g
-        out["start"][e], out["direction"][e], out["target"][e], out["speed"][e] = \
-            draw_agents(g, A, rng, graphs[e % len(variants)], depth=depth)
+        if scc_targets:
+            out["start"][e], out["direction"][e], out["target"][e], out["speed"][e] = \
+                draw_agents_scc(g, A, rng, graphs[e % len(variants)], depth=depth)
+        else:
+            out["start"][e], out["direction"][e], out["target"][e], out["speed"][e] = \
+                draw_agents(g, A, rng, graphs[e % len(variants)], depth=depth)
     return out

@@ -26,7 +26,7 @@ def _checksum(t):
     return int(flat[:n8].view(torch.int64).sum().item()) + int(flat[n8:].sum(dtype=torch.int64).item())
 
 
-@pytest.mark.parametrize("name,n_sample", [("cfg3", 12), ("cfg5", 2), ("cfg2", 24), ("cfg2g", 24)])
+@pytest.mark.parametrize("name,n_sample", [("cfg3", 12), ("cfg3g", 6), ("cfg5", 2), ("cfg2", 24), ("cfg2g", 24)])
 def test_full_size_workload(name, n_sample):
     import torch
     import flatland_marl_amd as fm
