@@ -159,23 +159,6 @@ def guarded_rollout_sample(out, rank, timeout_s, **kw):
     return res
 
 
-def masked_stream(device, n_cu, bits):
-    """A HIP stream whose kernels only run on the compute units named in `bits` (hipExtStreamCreateWithCUMask),
-    wrapped for torch."""
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    n_words = (n_cu + 31) // 32
-    words = (ctypes.c_uint32 * n_words)()
-    for b in bits:
-        words[b >> 5] |= 1 << (b & 31)
-    st = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(n_words), words)
-    if rc != 0 or not st.value:
-        raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
-    return torch.cuda.ExternalStream(st.value, device=device)
-
-
 def _free_port():
     import socket
     s = socket.socket()
@@ -240,11 +223,6 @@ def main():
     ap.add_argument("--obs-serial", type=int, default=1,
                     help="1: observation kernels run one after the other on the main stream after the other stages; "
                          "2: pipelined, the other stages of the next sub-batch run on a side stream meanwhile")
-    ap.add_argument("--front-cus", type=int, default=0,
-                    help="with --obs-serial 2: the side stream (graph .. columns) may only use this many compute units, "
-                         "the observation sweep the others (0: no masks)")
-    ap.add_argument("--cu-pattern", default="spread", choices=["spread", "low"],
-                    help="which bits of the compute-unit mask the side stream gets: every k-th bit, or the lowest ones")
     ap.add_argument("--paths", default="fused", choices=["fused", "dense"],
                     help="fused: paths and columns straight from the chain index (default when the tables fit the LDS); "
                          "dense: distance maps -> shortest paths -> columns as separate kernels")
@@ -278,134 +256,135 @@ def main():
         sys.stderr.write("bench.py: --gpus %d but the process group has %d ranks\n" % (args.gpus, n_ranks))
 
     data, E, A, depth, desc = workload_batch(args.workload, args.envs, seed=1000003 * rank)
-    # The batch is processed as `chunks` sub-batches spread over `streams` HIP streams, so that the
-    # latency-bound kernels of one sub-batch (graph, distances, paths) overlap the bandwidth-bound
-    # observation kernel of another.
-    n_chunks = max(1, min(args.chunks, E))
-    streams = [torch.cuda.Stream(device=device) for _ in range(max(1, args.streams))] if args.streams > 1 or n_chunks > 1 \
-        else [torch.cuda.current_stream(device)]
-    main_stream = torch.cuda.current_stream(device)
-    side_stream = streams[0]
-    if args.front_cus > 0 and args.obs_serial == 2:
-        n_cu = torch.cuda.get_device_properties(device).multi_processor_count
-        k = max(1, min(args.front_cus, n_cu - 1))
-        if args.cu_pattern == "low":
-            front_bits = set(range(k))
-        else:
-            front_bits = set(int(i * n_cu / k) for i in range(k))
-        side_stream = masked_stream(device, n_cu, front_bits)
-        main_stream = masked_stream(device, n_cu, set(range(n_cu)) - front_bits)
-        torch.cuda.set_stream(main_stream)
-    batches = []
-    for ci in range(n_chunks):
-        lo, hi = parallel.shard_range(E, ci, n_chunks)
-        st = streams[ci % len(streams)]
-        with torch.cuda.stream(st):
-            b = fm.ObservationBatch(data["grid"][lo:hi], data["start"][lo:hi], data["direction"][lo:hi],
-                                    data["target"][lo:hi], data["speed"][lo:hi], depth, device=device, stream=st)
-            b.build_graph(sync=True)
-        batches.append(b)
-    Rp = max(b.Rp for b in batches)          # one rail padding for the whole batch
-    for b in batches:
-        b.max_rails = Rp
-        b.Rp = Rp
-        b.plane_stride = plane_stride_for(Rp, b.T1)
-        with torch.cuda.stream(b.stream):
-            b.reset_fused(sync=True)         # sizes the rail axis (one host read-back), allocates every buffer
-    torch.cuda.synchronize()
-    batch = batches[0]
-    T1 = batch.T1
 
-    ready = [torch.cuda.Event() for _ in batches]
-    consumed = [None for _ in batches]
-
-    fused = args.paths == "fused" and all(b.fused_fits() for b in batches)
-
-    def front(b):
-        """Everything before the observation sweep: switch graph, state numbering, chain index, then either the
-        fused kernel (anchor distances + walks + columns in LDS) or dense distance maps -> walks -> columns."""
-        b.build_graph(sync=False)
-        if fused:
-            b.chain_index()
-            b.paths_columns_fused(shift=1, store_paths=not args.no_store_paths)
-        else:
-            b.compute_distances()
-            b.shortest_paths()
-            b.columns(shift=1)
-
-    def step_pipelined(ev=None):
-        # side stream: graph .. columns of sub-batch i+1 while the main stream writes the observations of sub-batch i
-        side = side_stream
-        for ci, b in enumerate(batches):
-            keep, b.stream = b.stream, side
-            with torch.cuda.stream(side):
-                if consumed[ci] is not None:
-                    side.wait_event(consumed[ci])       # the previous step's observation kernel has read the columns
-                front(b)
-                ready[ci].record(side)
-            main_stream.wait_event(ready[ci])
-            b.stream = main_stream
-            if ev is not None:
-                ev[ci][0].record(main_stream)
-            b.observations_fused()
-            if ev is not None:
-                ev[ci][1].record(main_stream)
-            consumed[ci] = torch.cuda.Event()
-            consumed[ci].record(main_stream)
-            b.stream = keep
-
-    def step(ev=None):
-        if args.obs_serial == 2:
-            return step_pipelined(ev)
-        for st in streams:
-            st.wait_stream(main_stream)
-        for ci, b in enumerate(batches):
+    def measure(chunks, n_streams, obs_serial):
+        """K timed passes of the observation path with the batch split into `chunks` sub-batches spread over
+        `n_streams` HIP streams; returns the wall time, the sweep's average launch duration and the batch facts."""
+        # The batch is processed as `chunks` sub-batches spread over `streams` HIP streams, so that the
+        # latency-bound kernels of one sub-batch (graph, distances, paths) overlap the bandwidth-bound
+        # observation kernel of another.
+        n_chunks = max(1, min(chunks, E))
+        streams = [torch.cuda.Stream(device=device) for _ in range(max(1, n_streams))] if n_streams > 1 or n_chunks > 1 \
+            else [torch.cuda.current_stream(device)]
+        main_stream = torch.cuda.current_stream(device)
+        batches = []
+        for ci in range(n_chunks):
+            lo, hi = parallel.shard_range(E, ci, n_chunks)
+            st = streams[ci % len(streams)]
+            with torch.cuda.stream(st):
+                b = fm.ObservationBatch(data["grid"][lo:hi], data["start"][lo:hi], data["direction"][lo:hi],
+                                        data["target"][lo:hi], data["speed"][lo:hi], depth, device=device, stream=st)
+                b.build_graph(sync=True)
+            batches.append(b)
+        Rp = max(b.Rp for b in batches)          # one rail padding for the whole batch
+        for b in batches:
+            b.max_rails = Rp
+            b.Rp = Rp
+            b.plane_stride = plane_stride_for(Rp, b.T1)
             with torch.cuda.stream(b.stream):
-                front(b)
-                if not args.obs_serial:
-                    if ev is not None:
-                        ev[ci][0].record(b.stream)
-                    b.observations_fused()
-                    if ev is not None:
-                        ev[ci][1].record(b.stream)
-        for st in streams:
-            main_stream.wait_stream(st)
-        if args.obs_serial:
+                b.reset_fused(sync=True)         # sizes the rail axis (one host read-back), allocates every buffer
+        torch.cuda.synchronize()
+        batch = batches[0]
+        T1 = batch.T1
+
+        ready = [torch.cuda.Event() for _ in batches]
+        consumed = [None for _ in batches]
+
+        fused = args.paths == "fused" and all(b.fused_fits() for b in batches)
+
+        def front(b):
+            """Everything before the observation sweep: switch graph, state numbering, chain index, then either the
+            fused kernel (anchor distances + walks + columns in LDS) or dense distance maps -> walks -> columns."""
+            b.build_graph(sync=False)
+            if fused:
+                b.chain_index()
+                b.paths_columns_fused(shift=1, store_paths=not args.no_store_paths)
+            else:
+                b.compute_distances()
+                b.shortest_paths()
+                b.columns(shift=1)
+
+        def step_pipelined(ev=None):
+            # side stream: graph .. columns of sub-batch i+1 while the main stream writes the observations of sub-batch i
+            side = streams[0]
             for ci, b in enumerate(batches):
+                keep, b.stream = b.stream, side
+                with torch.cuda.stream(side):
+                    if consumed[ci] is not None:
+                        side.wait_event(consumed[ci])       # the previous step's observation kernel has read the columns
+                    front(b)
+                    ready[ci].record(side)
+                main_stream.wait_event(ready[ci])
+                b.stream = main_stream
                 if ev is not None:
                     ev[ci][0].record(main_stream)
-                keep, b.stream = b.stream, main_stream
                 b.observations_fused()
-                b.stream = keep
                 if ev is not None:
                     ev[ci][1].record(main_stream)
+                consumed[ci] = torch.cuda.Event()
+                consumed[ci].record(main_stream)
+                b.stream = keep
 
-    for _ in range(args.warmup):
-        step()
-    events = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in batches]
-              for _ in range(args.steps)]
+        def step(ev=None):
+            if obs_serial == 2:
+                return step_pipelined(ev)
+            for st in streams:
+                st.wait_stream(main_stream)
+            for ci, b in enumerate(batches):
+                with torch.cuda.stream(b.stream):
+                    front(b)
+                    if not obs_serial:
+                        if ev is not None:
+                            ev[ci][0].record(b.stream)
+                        b.observations_fused()
+                        if ev is not None:
+                            ev[ci][1].record(b.stream)
+            for st in streams:
+                main_stream.wait_stream(st)
+            if obs_serial:
+                for ci, b in enumerate(batches):
+                    if ev is not None:
+                        ev[ci][0].record(main_stream)
+                    keep, b.stream = b.stream, main_stream
+                    b.observations_fused()
+                    b.stream = keep
+                    if ev is not None:
+                        ev[ci][1].record(main_stream)
 
-    def barrier():
+        for _ in range(args.warmup):
+            step()
+        events = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in batches]
+                  for _ in range(args.steps)]
+
+        def barrier():
+            torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(events[k])
         torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        barrier()
+        dt = parallel.max_over_ranks(dt, device)
+        for b in batches:
+            b.check_graph()
+        n_err = int(sum((b.agent_err != 0).sum().item() for b in batches))
+        # the observation kernel is launched once per sub-batch: average duration of one launch
+        obs_ms = float(np.mean([a.elapsed_time(b) for per_step in events for a, b in per_step]))
+        E_launch = batches[0].E
 
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(events[k])
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    barrier()
-    dt = parallel.max_over_ranks(dt, device)
-    for b in batches:
-        b.check_graph()
-    n_err = int(sum((b.agent_err != 0).sum().item() for b in batches))
-    # the observation kernel is launched once per sub-batch: average duration of one launch
-    obs_ms = float(np.mean([a.elapsed_time(b) for per_step in events for a, b in per_step]))
-    E_launch = batches[0].E
+        res = dict(dt=dt, obs_ms=obs_ms, E_launch=batches[0].E, Rp=int(Rp), T1=T1, n_err=n_err, n_chunks=n_chunks,
+                   n_streams=len(streams), fused=fused, plane_stride=batch.plane_stride)
+        return res
 
+    m = measure(args.chunks, args.streams, args.obs_serial)
+    torch.cuda.empty_cache()
+    dt, obs_ms, E_launch, Rp, T1, n_err = m["dt"], m["obs_ms"], m["E_launch"], m["Rp"], m["T1"], m["n_err"]
+    n_chunks, fused = m["n_chunks"], m["fused"]
     out = {}
     if rank == 0:
         total_obs = E * A * world * args.steps
@@ -420,8 +399,8 @@ def main():
             tj = json.load(open(tfile))
             traffic = tj.get("hbm_bytes_per_launch")
             if traffic is not None:
-                measured_on = float(tj.get("E", 4096)) * tj.get("A", A) * tj.get("plane_stride", batch.plane_stride)
-                traffic = traffic * (float(E_launch) * A * batch.plane_stride) / measured_on
+                measured_on = float(tj.get("E", 4096)) * tj.get("A", A) * tj.get("plane_stride", m["plane_stride"])
+                traffic = traffic * (float(E_launch) * A * m["plane_stride"]) / measured_on
         physical = None if traffic is None else traffic / (obs_ms * 1e-3) / 1e9
         out = {
             "metric": "agent-observations/sec (bitmap+heatmaps)",
@@ -438,7 +417,7 @@ def main():
             "dtype": "i8",
             "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, desc), "envs_per_gpu": E, "agents": A,
-                       "rails_padded": int(Rp), "depth": depth, "agents_flagged": n_err, "sub_batches": n_chunks, "streams": len(streams),
+                       "rails_padded": int(Rp), "depth": depth, "agents_flagged": n_err, "sub_batches": n_chunks, "streams": m["n_streams"],
                        "paths": ("fused" if fused else "dense") + ("" if not (fused and args.no_store_paths) else ", path elements not stored"),
                        "step": "graph build + chain index + anchor distances + shortest paths + occupancy columns + observations (dense planes are plane 0 of each observation)"},
             "roofline": {"kernel": "observations_columns_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0,

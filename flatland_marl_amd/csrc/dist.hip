@@ -27,9 +27,14 @@ __global__ __launch_bounds__(1024, 8) void chain_index_kernel(
     int capAnch, uint16_t* __restrict__ root_all, uint16_t* __restrict__ steps_all, uint32_t* __restrict__ edges_all,
     int32_t* __restrict__ n_anchor_all, int32_t* __restrict__ counts_all, uint16_t* __restrict__ succ_all,
     uint16_t* __restrict__ choice_all, uint16_t* __restrict__ walk_all, uint32_t* __restrict__ move_edge_all,
-    uint16_t* __restrict__ move_succ_all, const int32_t* __restrict__ idx_cell_all) {
+    uint16_t* __restrict__ move_succ_all, const int32_t* __restrict__ idx_cell_all,
+    unsigned long long* __restrict__ stamps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int e = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  auto stamp = [&](int i) {   // diagnostic only
+    if (stamps && threadIdx.x == 0) stamps[((size_t)2 * gridDim.x + blockIdx.x) * 16 + i] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
   const int HW = H * W;
   const int capS = capCells * 4;
   const int S = n_cells_all[e] * 4;
@@ -45,7 +50,7 @@ __global__ __launch_bounds__(1024, 8) void chain_index_kernel(
   uint16_t* stp1 = stp0 + capS;
   uint16_t* aidx = stp1 + capS;                          // [capS] anchor number or NONE
   unsigned* flags = reinterpret_cast<unsigned*>(aidx + capS + (capS & 1));  // [capS/32+1] anchor bits
-  int* scratch = reinterpret_cast<int*>(flags + (capS + 31) / 32 + 1);       // 16 ints
+  int* scratch = reinterpret_cast<int*>(flags + (capS + 31) / 32 + 1);       // 16 * 8 + 1 ints (multi_flag_counts)
   uint16_t* root = root_all + (size_t)e * capS;
   uint16_t* steps = steps_all + (size_t)e * capS;
   uint32_t* edges = edges_all + (size_t)e * capAnch * 4;
@@ -62,19 +67,23 @@ __global__ __launch_bounds__(1024, 8) void chain_index_kernel(
   }
   __syncthreads();
   // classify every state; successor of single-move states
-  for (int it = tid; it < n_visit; it += T) {
+  // the cell visited in pass `it`: its compact number, transition code and the compact numbers of the rail cells
+  // on the sides some heading may leave through (-1 = none)
+  auto visit = [&](int it, int& ci, unsigned& code, int (&nbr)[4]) -> bool {
     const int cell = idx_cell ? idx_cell[it] : it;
-    const int ci = idx_cell ? it : cell_idx[cell];
-    if (ci < 0) continue;
+    ci = idx_cell ? it : cell_idx[cell];
+    if (ci < 0) return false;
     const int r = cell / W, c = cell - r * W;
-    const unsigned code = grid[cell];
-    int nbr[4];   // compact number of the rail cell on each side some heading may leave through, -1 = none
+    code = grid[cell];
     const unsigned exits = (code | (code >> 4) | (code >> 8) | (code >> 12)) & 0xFu;
 #pragma unroll
     for (int n = 0; n < 4; n++) {
       const int nr = r + dr(n), nc = c + dc(n);
       nbr[n] = (has_exit(exits, n) && nr >= 0 && nr < H && nc >= 0 && nc < W) ? cell_idx[nr * W + nc] : -1;
     }
+    return true;
+  };
+  auto classify = [&](int ci, unsigned code, const int (&nbr)[4]) {
     const bool dead_end = __popc(code & 0xFFFFu) == 1;
 #pragma unroll
     for (int h = 0; h < 4; h++) {
@@ -123,8 +132,57 @@ __global__ __launch_bounds__(1024, 8) void chain_index_kernel(
         stp0[s] = 1;
       }
     }
+  };
+  // The first passes keep what they looked up in registers for the edge phase below (same thread, same cell): the
+  // look-ups are chains of dependent global loads.
+  constexpr int KI = 4;
+  unsigned kept_code[KI], kept_n01[KI], kept_n23[KI];
+  {
+    // three rounds of loads, none of them conditional (an index that does not exist reads a neighbouring one and
+    // the value is dropped), so that the loads of all passes are in flight together
+    int v_cell[KI], v_ci[KI], v_nbr[KI][4];
+    unsigned v_code[KI];
+    const int last = n_visit > 0 ? n_visit - 1 : 0;
+#pragma unroll
+    for (int k = 0; k < KI; k++) {
+      const int itc = min(k * T + tid, last);
+      v_cell[k] = idx_cell ? idx_cell[itc] : itc;
+      if (n_visit <= 0 || v_cell[k] < 0 || v_cell[k] >= HW) v_cell[k] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < KI; k++) {
+      v_code[k] = grid[v_cell[k]];
+      v_ci[k] = idx_cell ? min(k * T + tid, last) : cell_idx[v_cell[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < KI; k++) {
+      const int r = v_cell[k] / W, c = v_cell[k] - r * W;
+      const unsigned code = v_code[k];
+      const unsigned exits = (code | (code >> 4) | (code >> 8) | (code >> 12)) & 0xFu;
+#pragma unroll
+      for (int n = 0; n < 4; n++) {
+        const int nr = r + dr(n), nc = c + dc(n);
+        const bool ok = has_exit(exits, n) && nr >= 0 && nr < H && nc >= 0 && nc < W;
+        const int got = cell_idx[ok ? nr * W + nc : v_cell[k]];
+        v_nbr[k][n] = ok ? got : -1;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KI; k++) {
+      const bool live = k * T + tid < n_visit && v_ci[k] >= 0;
+      if (live) classify(v_ci[k], v_code[k], v_nbr[k]);
+      kept_code[k] = live ? (v_code[k] | 0x10000u | ((unsigned)v_ci[k] << 17)) : 0u;   // code, valid, compact number
+      kept_n01[k] = (unsigned)(v_nbr[k][0] & 0xFFFF) | ((unsigned)(v_nbr[k][1] & 0xFFFF) << 16);
+      kept_n23[k] = (unsigned)(v_nbr[k][2] & 0xFFFF) | ((unsigned)(v_nbr[k][3] & 0xFFFF) << 16);
+    }
+  }
+  for (int it = KI * T + tid; it < n_visit; it += T) {
+    int ci, nbr[4];
+    unsigned code;
+    if (visit(it, ci, code, nbr)) classify(ci, code, nbr);
   }
   __syncthreads();
+  stamp(1);
   if (succ_all) {
     uint16_t* succ = succ_all + (size_t)e * capS;
     for (int s = tid; s < S; s += T) succ[s] = aidx[s];
@@ -148,27 +206,28 @@ __global__ __launch_bounds__(1024, 8) void chain_index_kernel(
     t = sa; sa = sb; sb = t;
     if (!more) break;
   }
-  // number the anchors in state order
+  stamp(2);
+  // number the anchors in state order: eight strided passes over the states per ranking
   int n_anchor = 0;
-  for (int base = 0; base < S; base += T) {
-    const int s = base + tid;
-    const bool anc = s < S && ((flags[s >> 5] >> (s & 31)) & 1);
-    // 1024-thread flag scan: ballot per wave + wave totals through LDS
-    unsigned long long m = __ballot(anc);
-    const int w = tid >> 6;
-    if ((tid & 63) == 0) scratch[w] = __popcll(m);
-    __syncthreads();
-    int before = 0, tot = 0;
-    for (int i = 0; i < (T >> 6); i++) {
-      int v = scratch[i];
-      if (i < w) before += v;
-      tot += v;
+  constexpr int KB = 8;
+  for (int base0 = 0; base0 < S; base0 += KB * T) {
+    unsigned anc_bits = 0;
+#pragma unroll
+    for (int k = 0; k < KB; k++) {
+      const int s = base0 + k * T + tid;
+      if (s < S && ((flags[s >> 5] >> (s & 31)) & 1)) anc_bits |= 1u << k;
     }
-    __syncthreads();
-    if (s < S) aidx[s] = anc ? (uint16_t)min(n_anchor + before + __popcll(m & lanemask_lt()), 0xFFFE) : (uint16_t)FLM_NONE16;
+    const int tot = multi_flag_counts<KB>(anc_bits, scratch);
+#pragma unroll
+    for (int k = 0; k < KB; k++) {
+      const int s = base0 + k * T + tid;
+      const int rank = n_anchor + multi_flag_rank(anc_bits, k, scratch);
+      if (s < S) aidx[s] = ((anc_bits >> k) & 1u) ? (uint16_t)min(rank, 0xFFFE) : (uint16_t)FLM_NONE16;
+    }
     n_anchor += tot;
   }
   __syncthreads();
+  stamp(3);
   const bool overflow = n_anchor > capAnch;
   if (tid == 0) {
     n_anchor_all[e] = overflow ? capAnch : n_anchor;
@@ -191,54 +250,46 @@ __global__ __launch_bounds__(1024, 8) void chain_index_kernel(
       walk_all[(size_t)e * capS + s] = (uint16_t)wv;
     }
   }
+  stamp(4);
   // per anchor: one edge per move
-  for (int it = tid; it < n_visit; it += T) {
-    const int cell = idx_cell ? idx_cell[it] : it;
-    const int ci = idx_cell ? it : cell_idx[cell];
-    if (ci < 0) continue;
-    const int r = cell / W, c = cell - r * W;
-    const unsigned code = grid[cell];
+  auto emit_edges = [&](int ci, unsigned code, const int (&nbr)[4]) {
+    const bool dead_end = __popc(code & 0xFFFFu) == 1;
+#pragma unroll
     for (int h = 0; h < 4; h++) {
       const int s = ci * 4 + h;
       const unsigned a = aidx[s];
       if (a == FLM_NONE16 || a >= (unsigned)capAnch) continue;
       const int nib = nibble(code, h);
-      uint32_t out[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+      uint32_t o0 = 0xFFFFFFFFu, o1 = 0xFFFFFFFFu, o2 = 0xFFFFFFFFu, o3 = 0xFFFFFFFFu;   // the edges, packed to the front
+      uint32_t via[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};         // the edge through each side
       int k = 0;
+#pragma unroll
       for (int n = 0; n < 4; n++) {
-        if (!has_exit(nib, n)) continue;
-        const int nr = r + dr(n), nc = c + dc(n);
-        if (nr < 0 || nr >= H || nc < 0 || nc >= W) continue;
-        const int ni = cell_idx[nr * W + nc];
-        if (ni < 0) continue;
-        const int ns = ni * 4 + n;
-        const int j = ja[ns];
-        const unsigned aj = aidx[j];
+        if (!has_exit(nib, n) || nbr[n] < 0) continue;
+        const int ns = nbr[n] * 4 + n;
+        const unsigned aj = aidx[ja[ns]];
         if (aj == FLM_NONE16 || aj >= (unsigned)capAnch) continue;   // leads to a dead end or an endless loop
-        const unsigned w = 1u + sa[ns];
-        out[k++] = aj | (w << 16);
+        via[n] = aj | ((1u + sa[ns]) << 16);
+        if (k == 0) o0 = via[n];
+        else if (k == 1) o1 = via[n];
+        else if (k == 2) o2 = via[n];
+        else o3 = via[n];
+        k++;
       }
-      reinterpret_cast<uint4*>(edges)[a] = make_uint4(out[0], out[1], out[2], out[3]);
+      reinterpret_cast<uint4*>(edges)[a] = make_uint4(o0, o1, o2, o3);
       if (move_edge_all) {
         // the same edges in the order a path walk tries its moves (left, forward, right; in a dead end only the
         // U-turn, in the forward slot) beside the states those moves lead to; the fourth entries hold the flag
         // "the move is reported as forward" (a single exit, or the U-turn of a dead end)
         uint32_t me[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
         unsigned ms[3] = {FLM_NONE16, FLM_NONE16, FLM_NONE16};
-        const bool dead_end = __popc(code & 0xFFFFu) == 1;
+#pragma unroll
         for (int i = 0; i < 3; i++) {
           const int d = dead_end ? ((h + 2) & 3) : ((h + i + 3) & 3);
           if (dead_end && i != 1) continue;
-          if (!has_exit(nib, d)) continue;
-          const int nr = r + dr(d), nc = c + dc(d);
-          if (nr < 0 || nr >= H || nc < 0 || nc >= W) continue;
-          const int ni = cell_idx[nr * W + nc];
-          if (ni < 0) continue;
-          const int ns = ni * 4 + d;
-          ms[i] = (unsigned)ns;
-          const unsigned aj = aidx[ja[ns]];
-          if (aj == FLM_NONE16 || aj >= (unsigned)capAnch) continue;
-          me[i] = aj | ((1u + sa[ns]) << 16);
+          if (!has_exit(nib, d) || nbr[d] < 0) continue;
+          ms[i] = (unsigned)(nbr[d] * 4 + d);
+          me[i] = via[d];
         }
         const unsigned single = (dead_end || __popc(nib) == 1) ? 1u : 0u;
         reinterpret_cast<uint4*>(move_edge_all + (size_t)e * capAnch * 4)[a] = make_uint4(me[0], me[1], me[2], single);
@@ -246,7 +297,20 @@ __global__ __launch_bounds__(1024, 8) void chain_index_kernel(
             make_uint2(ms[0] | (ms[1] << 16), ms[2] | (single << 16));
       }
     }
+  };
+#pragma unroll
+  for (int k = 0; k < KI; k++) {
+    if (!(kept_code[k] & 0x10000u)) continue;
+    const int nbr[4] = {(int)(int16_t)(kept_n01[k] & 0xFFFFu), (int)(int16_t)(kept_n01[k] >> 16),
+                        (int)(int16_t)(kept_n23[k] & 0xFFFFu), (int)(int16_t)(kept_n23[k] >> 16)};
+    emit_edges((int)(kept_code[k] >> 17), kept_code[k] & 0xFFFFu, nbr);
   }
+  for (int it = KI * T + tid; it < n_visit; it += T) {
+    int ci, nbr[4];
+    unsigned code;
+    if (visit(it, ci, code, nbr)) emit_edges(ci, code, nbr);
+  }
+  stamp(5);
 }
 
 // One workgroup per (environment, 32 target slots).  LDS: the anchors' out-edges and, per group of four
@@ -359,14 +423,14 @@ extern "C" int flm_chain_index(const uint16_t* grid, const int32_t* cell_idx, co
   if (E <= 0 || A <= 0 || H <= 0 || W <= 0 || capCells <= 0 || capCells * 4 >= 65535 || capAnch <= 0 || capAnch > 0xFFF0)
     return FLM_E_ARG;
   const size_t capS = (size_t)capCells * 4;
-  size_t lds = capS * 2 * 5 + 16 + ((capS + 31) / 32 + 1) * 4 + 128;
+  size_t lds = capS * 2 * 5 + 16 + ((capS + 31) / 32 + 1) * 4 + 4 * (16 * 8 + 1) + 64;
   if (lds > 160 * 1024 - 512) return FLM_E_ARG;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(flm::chain_index_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds) != hipSuccess)
     return FLM_E_LAUNCH;
   hipLaunchKernelGGL(flm::chain_index_kernel, dim3(E), dim3(1024), lds, (hipStream_t)stream, grid, cell_idx, n_cells,
                      target_cell, A, H, W, capCells, capAnch, root, steps, edges, n_anchor, counts, succ, choice, walk,
-                     move_edge, move_succ, idx_cell);
+                     move_edge, move_succ, idx_cell, g_flm_stamps);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }

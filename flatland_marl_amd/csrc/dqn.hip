@@ -8,6 +8,8 @@
 // Parameters live in one flat fp32 buffer in the order of the module's parameters():
 //   conv1.weight[64,T1] conv1.bias[64] fc1_adv.weight[512,K1] fc1_adv.bias[512] fc1_val.weight[512,K1]
 //   fc1_val.bias[512] fc2_adv.weight[2,512] fc2_adv.bias[2] fc2_val.weight[1,512] fc2_val.bias[1],  K1 = 64*H3.
+#include <type_traits>
+
 #include "flm_common.h"
 
 namespace flm {
@@ -56,6 +58,8 @@ struct GemmArgs {
                        // selects an independent product: A += group*a_zs, B += group*b_zs, C += group*c_gs
   int groups;
   long c_gs;
+  int b_break_k;       // > 0 (B not k-contiguous only): rows k >= b_break_k of B start b_break_off floats further on
+  long b_break_off;    // (two [K/2, N] blocks that are not adjacent in memory multiplied as one [K, N] matrix)
 };
 
 #define GBM 128
@@ -69,7 +73,7 @@ struct GemmArgs {
 // otherwise the source is m/n-contiguous (thread reads 4 consecutive rows of one k).
 template <bool KC>
 __device__ __forceinline__ void fetch_tile(const float* __restrict__ P, long ld, int r0, int rmax, int k0, int kmax, bool vec,
-                                           int tid, float (&v)[2][4]) {
+                                           int tid, float (&v)[2][4], int break_k = 0, long break_off = 0) {
 #pragma unroll
   for (int rep = 0; rep < 2; rep++) {
     if (KC) {
@@ -84,7 +88,7 @@ __device__ __forceinline__ void fetch_tile(const float* __restrict__ P, long ld,
       }
     } else {
       const int k = k0 + (tid >> 5) + rep * 8, r = r0 + (tid & 31) * 4;
-      const float* p = P + (long)k * ld + r;
+      const float* p = P + (long)k * ld + r + ((break_k > 0 && k >= break_k) ? break_off : 0);
       if (vec && k < kmax && r + 3 < rmax) {
         const float4 t = *reinterpret_cast<const float4*>(p);
         v[rep][0] = t.x; v[rep][1] = t.y; v[rep][2] = t.z; v[rep][3] = t.w;
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmArgs g) {
   const int k_end = g.ksplit ? min(g.K, k_begin + g.ksplit) : g.K;
   // 16-byte fetches need the rows 16-byte aligned
   const bool a_vec = (g.lda & 3) == 0 && (reinterpret_cast<size_t>(A) & 15) == 0;
-  const bool b_vec = (g.ldb & 3) == 0 && (reinterpret_cast<size_t>(B) & 15) == 0;
+  const bool b_vec = (g.ldb & 3) == 0 && (reinterpret_cast<size_t>(B) & 15) == 0 && (g.b_break_off & 3) == 0;
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; i++)
@@ -141,14 +145,14 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmArgs g) {
   // software pipeline: the next K slice is fetched into registers while the matrix cores work on the one in LDS
   float ra[2][4], rb[2][4];
   fetch_tile<A_KC>(A, g.lda, m0, g.M, k_begin, k_end, a_vec, tid, ra);
-  fetch_tile<B_KC>(B, g.ldb, n0, g.N, k_begin, k_end, b_vec, tid, rb);
+  fetch_tile<B_KC>(B, g.ldb, n0, g.N, k_begin, k_end, b_vec, tid, rb, g.b_break_k, g.b_break_off);
   for (int k0 = k_begin; k0 < k_end; k0 += GBK) {
     place_tile<A_KC>(As, tid, ra);
     place_tile<B_KC>(Bs, tid, rb);
     __syncthreads();
     if (k0 + GBK < k_end) {
       fetch_tile<A_KC>(A, g.lda, m0, g.M, k0 + GBK, k_end, a_vec, tid, ra);
-      fetch_tile<B_KC>(B, g.ldb, n0, g.N, k0 + GBK, k_end, b_vec, tid, rb);
+      fetch_tile<B_KC>(B, g.ldb, n0, g.N, k0 + GBK, k_end, b_vec, tid, rb, g.b_break_k, g.b_break_off);
     }
 #pragma unroll
     for (int kk = 0; kk < GBK; kk += 2) {
@@ -281,6 +285,39 @@ __global__ __launch_bounds__(1024) void conv_bias_grad_kernel(const float* __res
   }
 }
 
+// ---- small-batch convolution (act: B <= 8, float input) -----------------------------------------------------
+// x1[b][c][h] = relu(bias[c] + sum_k x[b][h][k] * Wc[c][k]) for four rows (b,h) per workgroup: the filter bank is
+// staged in LDS transposed ([k][c], padded so that neither the staging nor the reads conflict), thread (c, r)
+// owns one output, and the four rows of one filter leave as one 16-byte run.
+__global__ __launch_bounds__(256) void conv_rows_kernel(const float* __restrict__ X, const float* __restrict__ Wc,
+                                                        const float* __restrict__ bias, long M, int T1, int H3,
+                                                        float* __restrict__ x1) {
+  extern __shared__ __attribute__((aligned(16))) float conv_lds[];
+  float* wt = conv_lds;                    // [T1][65]
+  float* xs = conv_lds + (size_t)T1 * 65;  // [4][T1]
+  const int tid = threadIdx.x;
+  const long row0 = (long)blockIdx.x * 4;
+  for (int i = tid; i < 64 * T1; i += 256) {
+    const int c = i / T1, k = i - c * T1;
+    wt[k * 65 + c] = Wc[i];
+  }
+  for (int i = tid; i < 4 * T1; i += 256) {
+    const long row = row0 + i / T1;
+    xs[i] = row < M ? X[row0 * T1 + i] : 0.f;
+  }
+  __syncthreads();
+  const int c = tid >> 2, r = tid & 3;
+  const float* xr = xs + r * T1;
+  float acc = 0.f;
+  for (int k = 0; k < T1; k++) acc = fmaf(xr[k], wt[k * 65 + c], acc);
+  const long row = row0 + r;
+  if (row < M) {
+    const long b = row / H3, h = row - b * H3;
+    const float v = acc + bias[c];
+    x1[(b * 64 + c) * H3 + h] = v > 0.f ? v : 0.f;
+  }
+}
+
 // ---- small-batch first dense layer (act: B <= 8): one wave per output neuron streams its weight row
 template <int BMAX>
 __global__ __launch_bounds__(256) void fc1_small_kernel(const float* __restrict__ X, const float* __restrict__ W,
@@ -338,27 +375,25 @@ __global__ __launch_bounds__(1024) void fc1_rows_kernel(const float* __restrict_
   for (int r = 0; r < R; r++)
 #pragma unroll
     for (int b = 0; b < BMAX; b++) acc[r][b] = 0.f;
-  for (long i0 = tid; i0 < K4; i0 += 4 * 1024) {         // four pieces of every row per trip
-    float4 w[4][R], x[4][BMAX];
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  // U pieces of every row per trip, all loads of a trip issued before the first product (no load is conditional)
+  auto trip = [&](long i0, auto u_count) {
+    constexpr int U = decltype(u_count)::value;
+    v4f w[U][R];
+    float4 x[U][BMAX];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < U; u++) {
       const long i = i0 + (long)u * 1024;
-      const bool in = i < K4;
 #pragma unroll
       for (int r = 0; r < R; r++)
-        if (in) {
-          typedef float v4f __attribute__((ext_vector_type(4)));
-          const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(W + (long)r * K) + i);   // read once
-          w[u][r] = make_float4(t.x, t.y, t.z, t.w);
-        } else {
-          w[u][r] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        w[u][r] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(W + (long)r * K) + i);   // read once
 #pragma unroll
       for (int b = 0; b < BMAX; b++)
-        x[u][b] = (in && b < B) ? reinterpret_cast<const float4*>(X + (long)b * K)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        x[u][b] = reinterpret_cast<const float4*>(X + (long)(b < B ? b : 0) * K)[i];
     }
+    __builtin_amdgcn_sched_barrier(0);   // every load of the trip is in flight before the first product waits
 #pragma unroll
-    for (int u = 0; u < 4; u++)
+    for (int u = 0; u < U; u++)
 #pragma unroll
       for (int r = 0; r < R; r++)
 #pragma unroll
@@ -368,7 +403,11 @@ __global__ __launch_bounds__(1024) void fc1_rows_kernel(const float* __restrict_
           acc[r][b] = fmaf(w[u][r].z, x[u][b].z, acc[r][b]);
           acc[r][b] = fmaf(w[u][r].w, x[u][b].w, acc[r][b]);
         }
-  }
+  };
+  constexpr int UT = BMAX == 1 ? 4 : (BMAX <= 4 ? 2 : 1);   // pieces per trip: what the registers hold beside x
+  long i0 = tid;
+  for (; i0 + (UT - 1) * 1024 < K4; i0 += UT * 1024) trip(i0, std::integral_constant<int, UT>{});
+  for (; i0 < K4; i0 += 1024) trip(i0, std::integral_constant<int, 1>{});
 #pragma unroll
   for (int r = 0; r < R; r++)
 #pragma unroll
@@ -867,7 +906,16 @@ static int dqn_forward_impl(const float* params, const float* x, const uint8_t* 
   DqnLayout L(H3, T1);
   GemmArgs g{};
   int rc;
-  if (x) {
+  // small batches (act): the first dense layer streams both weight matrices in one launch
+  const bool rows_path = B <= 8 && (L.K1 & 3) == 0 &&
+                         (((uintptr_t)(params + L.a1_w) | (uintptr_t)(params + L.v1_w) | (uintptr_t)x1) & 15) == 0;
+  const size_t conv_rows_lds = sizeof(float) * ((size_t)T1 * 65 + 4 * (size_t)T1);
+  if (x && rows_path && conv_rows_lds <= 64 * 1024) {
+    const long M = (long)B * H3;
+    hipLaunchKernelGGL(flm::conv_rows_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), conv_rows_lds, stream, x,
+                       params + L.conv_w, params + L.conv_b, M, T1, H3, x1);
+    if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
+  } else if (x) {
     // conv as GEMM: rows (b,h), K = T1, 64 filters; stored as [b][c][h] with ReLU
     g.A = x; g.B = params + L.conv_w; g.C = x1; g.bias = params + L.conv_b; g.mask = nullptr;
     g.M = B * H3; g.N = 64; g.K = T1; g.lda = T1; g.ldb = T1; g.ldc = 0; g.a_zs = g.b_zs = g.c_zs = 0;
@@ -891,7 +939,7 @@ static int dqn_forward_impl(const float* params, const float* x, const uint8_t* 
       rc = FLM_E_ARG;
     if (rc) return rc;
   }
-  if (B <= 8 && (L.K1 & 3) == 0 && (((uintptr_t)(params + L.a1_w) | (uintptr_t)(params + L.v1_w) | (uintptr_t)x1) & 15) == 0) {
+  if (rows_path) {
     if (B == 1)
       hipLaunchKernelGGL(flm::fc1_rows_kernel<1>, dim3(256), dim3(1024), 0, stream, x1, params + L.a1_w, params + L.v1_w,
                          params + L.a1_b, params + L.v1_b, B, L.K1, hid);
@@ -1015,23 +1063,26 @@ static int learn_grads_impl(const float* local, const float* target, const float
   hipLaunchKernelGGL(flm::head_backward_params_kernel, dim3(8), dim3(1024), 0, stream, hid, dadv, dval, B, grads + L.a2_w,
                      grads + L.a2_b, grads + L.v2_w, grads + L.v2_b);
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
-  // first dense layer: weight gradients dW[n,j] = sum_b dhid[b,n] * x1[b,j]; bias gradients = column sums
-  for (int st = 0; st < 2; st++) {
+  // first dense layer: weight gradients dW[n,j] = sum_b dhid[b,n] * x1[b,j], both streams as two groups of one launch
+  // (more workgroups per launch: fewer idle matrix pipes in the last round); bias gradients = column sums
+  {
     GemmArgs g{};
-    g.A = dhid + st * 512; g.B = x1; g.C = grads + (st ? L.v1_w : L.a1_w);
+    g.A = dhid; g.B = x1; g.C = grads + L.a1_w;
     g.M = 512; g.N = (int)L.K1; g.K = B; g.lda = 1024; g.ldb = L.K1; g.ldc = L.K1;
-    if ((rc = flm::launch_gemm<false, false, flm::EPI_PLAIN>(g, 1, stream))) return rc;
-    hipLaunchKernelGGL(flm::colsum_kernel, dim3(8), dim3(1024), 0, stream, dhid + st * 512, B, 512, 1024L,
-                       grads + (st ? L.v1_b : L.a1_b));
+    g.ksplit = B; g.groups = 2; g.a_zs = 512; g.b_zs = 0; g.c_zs = 0; g.c_gs = L.v1_w - L.a1_w;
+    if ((rc = flm::launch_gemm<false, false, flm::EPI_PLAIN>(g, 2, stream))) return rc;
+    for (int st = 0; st < 2; st++)
+      hipLaunchKernelGGL(flm::colsum_kernel, dim3(8), dim3(1024), 0, stream, dhid + st * 512, B, 512, 1024L,
+                         grads + (st ? L.v1_b : L.a1_b));
   }
-  // gradient w.r.t. the conv activations: dx1 = dhid_adv * W_adv + dhid_val * W_val, zero where x1 == 0
-  for (int st = 0; st < 2; st++) {
+  // gradient w.r.t. the conv activations: dx1 = [dhid_adv dhid_val] * [W_adv; W_val], zero where x1 == 0: one product
+  // over K = 1024 (the two weight blocks are not adjacent: the value block starts v1_w - a1_w - 512*K1 floats late)
+  {
     GemmArgs g{};
-    g.A = dhid + st * 512; g.B = local + (st ? L.v1_w : L.a1_w); g.C = dx1; g.mask = x1;
-    g.M = B; g.N = (int)L.K1; g.K = 512; g.lda = 1024; g.ldb = L.K1; g.ldc = L.K1; g.accumulate = st;
-    if (st == 0) rc = flm::launch_gemm<true, false, flm::EPI_PLAIN>(g, 1, stream);
-    else rc = flm::launch_gemm<true, false, flm::EPI_MASK>(g, 1, stream);
-    if (rc) return rc;
+    g.A = dhid; g.B = local + L.a1_w; g.C = dx1; g.mask = x1;
+    g.M = B; g.N = (int)L.K1; g.K = 1024; g.lda = 1024; g.ldb = L.K1; g.ldc = L.K1;
+    g.b_break_k = 512; g.b_break_off = (L.v1_w - L.a1_w) - 512L * L.K1;
+    if ((rc = flm::launch_gemm<true, false, flm::EPI_MASK>(g, 1, stream))) return rc;
   }
   // conv weights: per sample dWc_b[64,T1] = dx1_b[64,H3] * s_b[H3,T1], then a fixed-order sum over the batch
   {

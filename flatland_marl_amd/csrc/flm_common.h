@@ -69,6 +69,53 @@ __device__ __forceinline__ int block_flag_scan(bool flag, int* scratch, int* tot
   return base + within;
 }
 
+// K flags per thread (bit k of `bits`), ranked in the order (k, thread) - the order of a strided loop
+// `for (k) item = k * blockDim.x + threadIdx.x` - with three barriers for all K instead of two per flag.
+// multi_flag_counts leaves the exclusive prefix of every (k, wave) and the total in scratch (16 * K + 1 ints of LDS)
+// and returns the total; multi_flag_rank then gives the rank of this thread's flag k.
+template <int K>
+__device__ __forceinline__ int multi_flag_counts(unsigned bits, int* scratch) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();   // an earlier use of scratch is over
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const unsigned long long m = __ballot((bits >> k) & 1u);
+    if (lane == 0) scratch[k * 16 + w] = __popcll(m);
+  }
+  __syncthreads();
+  if (w == 0) {
+    constexpr int C = (16 * K + 63) / 64;   // consecutive entries per lane
+    int v[C], sum = 0;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+      const int i = lane * C + c;
+      v[c] = (i < 16 * K && (i & 15) < nw) ? scratch[i] : 0;
+      sum += v[c];
+    }
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
+    }
+    int run = inc - sum;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+      const int i = lane * C + c;
+      if (i < 16 * K) scratch[i] = run;
+      run += v[c];
+    }
+    if (lane == 63) scratch[16 * K] = inc;
+  }
+  __syncthreads();
+  return scratch[16 * K];
+}
+
+__device__ __forceinline__ int multi_flag_rank(unsigned bits, int k, const int* scratch) {
+  const unsigned long long m = __ballot((bits >> k) & 1u);
+  return scratch[k * 16 + (threadIdx.x >> 6)] + __popcll(m & lanemask_lt());
+}
+
 // Exclusive prefix sum of a per-thread int over the workgroup (up to 1024 threads), plus the workgroup total.
 __device__ __forceinline__ int block_int_scan(int v, int* scratch, int* total) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
@@ -216,3 +263,9 @@ __device__ __forceinline__ int greedy_path(const uint16_t* __restrict__ grid, co
 }
 
 }  // namespace flm
+// Diagnostic only (flm_debug_fused_stamps): when set, the one-workgroup-per-environment kernels of the reset path
+// write shader-clock stamps at their phase boundaries to this device buffer, [3][E][16] 64-bit words
+// (0: anchor_decisions / walk_columns, 1: graph_build, 2: chain_index).  Nothing else reads it.
+extern unsigned long long* g_flm_stamps;
+
+

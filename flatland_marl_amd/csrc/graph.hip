@@ -61,9 +61,14 @@ template <bool LDS_GRID>
 __global__ __launch_bounds__(1024, 8) void graph_build_kernel(
     const uint16_t* __restrict__ grid_all, int H, int W, int capN, int capR, int capC, int32_t* __restrict__ node_id_all,
     int32_t* __restrict__ node_cell_all, int32_t* __restrict__ edge_info_all, int32_t* __restrict__ edge_cell_off_all,
-    int32_t* __restrict__ edge_cells_all, int32_t* __restrict__ cell_rail_all, int32_t* __restrict__ counts_all) {
+    int32_t* __restrict__ edge_cells_all, int32_t* __restrict__ cell_rail_all, int32_t* __restrict__ counts_all,
+    unsigned long long* __restrict__ stamps) {
   extern __shared__ __attribute__((aligned(16))) int lds[];
   const int e = blockIdx.x;
+  auto stamp = [&](int i) {   // diagnostic only
+    if (stamps && threadIdx.x == 0) stamps[((size_t)gridDim.x + blockIdx.x) * 16 + i] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
   const int HW = H * W;
   const uint16_t* grid_g = grid_all + (size_t)e * HW;
   int32_t* node_id = node_id_all + (size_t)e * HW;
@@ -75,7 +80,8 @@ __global__ __launch_bounds__(1024, 8) void graph_build_kernel(
   int32_t* counts = counts_all + (size_t)e * 4;
 
   int* scratch = lds;                 // 16 ints
-  int* p_end = lds + 16;              // [4*capN]
+  int* mscan = lds + 16;              // 16 * 8 + 1 ints (multi_flag_counts); 272 reserved
+  int* p_end = lds + 16 + 272;        // [4*capN]
   int* p_len = p_end + 4 * capN;      // [4*capN]
   int* p_first = p_len + 4 * capN;    // [4*capN]
   int* conn = p_first + 4 * capN;     // [capN] connection mask per node
@@ -85,40 +91,56 @@ __global__ __launch_bounds__(1024, 8) void graph_build_kernel(
   const int tid = threadIdx.x, T = blockDim.x;
   int err = 0;
 
-  // ---- nodes: row-major numbering
+  // ---- nodes: row-major numbering, eight strided passes over the cells per ranking (multi_flag_counts)
+  constexpr int KB = 8;
   int n_nodes = 0;
-  for (int base = 0; base < HW; base += T) {
-    int cell = base + tid;
-    bool is_node = false;
-    int mask = 0;
-    if (cell < HW) {
-      unsigned code = grid_g[cell];
-      if (LDS_GRID) l_code[cell] = (uint16_t)code;
-      if (code == 0x8421u) {
-        is_node = true;
-        mask = 0xF;
-      } else {
+  for (int base0 = 0; base0 < HW; base0 += KB * T) {
+    unsigned node_bits = 0;
+    unsigned codes[KB];
 #pragma unroll
-        for (int d = 0; d < 4; d++) {
-          int nib = nibble(code, d);
-          if (nib) mask |= 1 << ((d + 2) & 3);
+    for (int k = 0; k < KB; k++) codes[k] = grid_g[min(base0 + k * T + tid, HW - 1)];   // unconditional: all in flight at once
 #pragma unroll
-          for (int t = 0; t < 4; t++)
-            if (has_exit(nib, t)) mask |= 1 << t;
-          if (__popc(nib) > 1) is_node = true;
-        }
+    for (int k = 0; k < KB; k++) {
+      const int cell = base0 + k * T + tid;
+      if (cell < HW) {
+        const unsigned code = codes[k];
+        if (LDS_GRID) l_code[cell] = (uint16_t)code;
+        // a switch: some heading has a choice of exits; the diamond crossing counts as one as well
+        const bool is_node = code == 0x8421u || __popc(code & 0xFu) > 1 || __popc(code & 0xF0u) > 1 ||
+                             __popc(code & 0xF00u) > 1 || __popc(code & 0xF000u) > 1;
+        cell_rail[cell] = -1;
+        if (is_node) node_bits |= 1u << k;
       }
-      cell_rail[cell] = -1;
     }
-    int tot;
-    int id = n_nodes + block_flag_scan(is_node, scratch, &tot);
-    if (cell < HW) {
-      node_id[cell] = (is_node && id < capN) ? id : -1;
-      if (LDS_GRID) l_node[cell] = (int16_t)((is_node && id < capN) ? id : -1);
-    }
-    if (is_node && id < capN) {
-      node_cell[id] = cell;
-      conn[id] = mask;
+    const int tot = multi_flag_counts<KB>(node_bits, mscan);
+#pragma unroll
+    for (int k = 0; k < KB; k++) {
+      const int cell = base0 + k * T + tid;
+      const bool is_node = (node_bits >> k) & 1u;
+      const int id = n_nodes + multi_flag_rank(node_bits, k, mscan);
+      if (cell < HW) {
+        node_id[cell] = (is_node && id < capN) ? id : -1;
+        if (LDS_GRID) l_node[cell] = (int16_t)((is_node && id < capN) ? id : -1);
+      }
+      if (is_node && id < capN) {
+        // sides with a connection: where some heading may leave to, and where it comes in from
+        const unsigned code = grid_g[cell];
+        unsigned mask = 0;
+        if (code == 0x8421u) {
+          mask = 0xF;
+        } else {
+#pragma unroll
+          for (int d = 0; d < 4; d++) {
+            const int nib = nibble(code, d);
+            if (nib) mask |= 1u << ((d + 2) & 3);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+              if (has_exit(nib, t)) mask |= 1u << t;
+          }
+        }
+        node_cell[id] = cell;
+        conn[id] = (int)mask;
+      }
     }
     n_nodes += tot;
   }
@@ -127,6 +149,7 @@ __global__ __launch_bounds__(1024, 8) void graph_build_kernel(
     n_nodes = capN;
   }
   __syncthreads();  // node_id / node_cell / conn visible to the whole workgroup
+  stamp(1);
 
   // ---- every connected port walks to the next node
   const int n_ports = n_nodes * 4;
@@ -143,6 +166,7 @@ __global__ __launch_bounds__(1024, 8) void graph_build_kernel(
     }
   }
   __syncthreads();
+  stamp(2);
   for (int p = tid; p < n_ports; p += T) {
     int q = p_end[p];
     if (q >= 0) {
@@ -153,6 +177,7 @@ __global__ __launch_bounds__(1024, 8) void graph_build_kernel(
   }
   __syncthreads();
 
+  stamp(3);
   // ---- edge ids = prefix count of creating ports; cell offsets = prefix sum of their lengths
   int n_edges = 0, n_cells = 0;
   for (int base = 0; base < n_ports; base += T) {
@@ -185,6 +210,7 @@ __global__ __launch_bounds__(1024, 8) void graph_build_kernel(
     n_edges += tot_e;
     n_cells += tot_c;
   }
+  stamp(4);
   if (n_edges > capR) err |= FLM_GRAPH_ERR_RAILS;
   if (n_cells > capC) err |= FLM_GRAPH_ERR_CELLS;
   if (tid == 0) {
@@ -201,30 +227,29 @@ __global__ __launch_bounds__(1024) void state_index_kernel(const uint16_t* __res
                                                            int32_t* __restrict__ cell_idx_all, int32_t* __restrict__ n_cells_all,
                                                            uint16_t* __restrict__ pred_all, int32_t* __restrict__ counts_all,
                                                            int32_t* __restrict__ idx_cell_all) {
-  __shared__ int wave_tot[16];
+  __shared__ int mscan[16 * 16 + 1];
   const int e = blockIdx.x, tid = threadIdx.x, HW = H * W;
-  const int wave = tid >> 6;
   const uint16_t* grid = grid_all + (size_t)e * HW;
   int32_t* cell_idx = cell_idx_all + (size_t)e * HW;
+  constexpr int KB = 16;   // strided passes over the cells per ranking
   int n = 0;
-  for (int base = 0; base < HW; base += 1024) {
-    const int cell = base + tid;
-    const bool rail = cell < HW && grid[cell] != 0;
-    // 1024-thread flag scan: ballot per wave + wave totals through LDS
-    const unsigned long long m = __ballot(rail);
-    if ((tid & 63) == 0) wave_tot[wave] = __popcll(m);
-    __syncthreads();
-    int before = 0, tot = 0;
+  for (int base0 = 0; base0 < HW; base0 += KB * 1024) {
+    unsigned rail_bits = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int v = wave_tot[i];
-      if (i < wave) before += v;
-      tot += v;
+    for (int k = 0; k < KB; k++) {
+      const int cell = base0 + k * 1024 + tid;
+      const unsigned code = grid[min(cell, HW - 1)];   // unconditional: all loads in flight at once
+      if (cell < HW && code != 0) rail_bits |= 1u << k;
     }
-    __syncthreads();
-    const int id = n + before + __popcll(m & lanemask_lt());
-    if (cell < HW) cell_idx[cell] = (rail && id < capCells) ? id : -1;
-    if (idx_cell_all && rail && id < capCells) idx_cell_all[(size_t)e * capCells + id] = cell;
+    const int tot = multi_flag_counts<KB>(rail_bits, mscan);
+#pragma unroll
+    for (int k = 0; k < KB; k++) {
+      const int cell = base0 + k * 1024 + tid;
+      const bool rail = (rail_bits >> k) & 1u;
+      const int id = n + multi_flag_rank(rail_bits, k, mscan);
+      if (cell < HW) cell_idx[cell] = (rail && id < capCells) ? id : -1;
+      if (idx_cell_all && rail && id < capCells) idx_cell_all[(size_t)e * capCells + id] = cell;
+    }
     n += tot;
   }
   if (tid == 0) {
@@ -268,7 +293,7 @@ extern "C" int flm_graph_build(const uint16_t* grid, int E, int H, int W, int ca
   if (!grid || !node_id || !node_cell || !edge_info || !edge_cell_off || !edge_cells || !cell_rail || !counts)
     return FLM_E_ARG;
   if (E <= 0 || H <= 0 || W <= 0 || capN <= 0 || capN > FLM_MAX_NODES || capR <= 0 || capC <= 0) return FLM_E_ARG;
-  const size_t lds_ports = sizeof(int) * (16 + (size_t)capN * 13);
+  const size_t lds_ports = sizeof(int) * (16 + 272 + (size_t)capN * 13);
   const size_t lds_grid = lds_ports + 4 * (size_t)H * W;
   // stage the grid in LDS when two workgroups still fit a CU (80 KB each)
   const bool staged = lds_grid <= 80 * 1024;
@@ -279,10 +304,10 @@ extern "C" int flm_graph_build(const uint16_t* grid, int E, int H, int W, int ca
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return FLM_E_LAUNCH;
   if (staged)
     hipLaunchKernelGGL(flm::graph_build_kernel<true>, dim3(E), dim3(1024), lds, (hipStream_t)stream, grid, H, W, capN, capR,
-                       capC, node_id, node_cell, edge_info, edge_cell_off, edge_cells, cell_rail, counts);
+                       capC, node_id, node_cell, edge_info, edge_cell_off, edge_cells, cell_rail, counts, g_flm_stamps);
   else
     hipLaunchKernelGGL(flm::graph_build_kernel<false>, dim3(E), dim3(1024), lds, (hipStream_t)stream, grid, H, W, capN, capR,
-                       capC, node_id, node_cell, edge_info, edge_cell_off, edge_cells, cell_rail, counts);
+                       capC, node_id, node_cell, edge_info, edge_cell_off, edge_cells, cell_rail, counts, g_flm_stamps);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }

@@ -8,6 +8,8 @@ O=gpurun_out/prof_c
 mkdir -p $O
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $O/bench -o bench --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-rollout > $O/bench.log 2>&1
 echo "bench stats done"
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $O/bench_g -o bench --output-format csv -- python3 bench.py --workload cfg3g --steps 5 --warmup 1 --no-cpu-baseline --no-rollout > $O/bench_g.log 2>&1
+echo "bench cfg3g stats done"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $O/dqn -o dqn --output-format csv -- python3 tools/dqn_bench.py > $O/dqn.log 2>&1
 echo "dqn stats done"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $O/rollout -o rollout --output-format csv -- python3 tools/rollout_bench.py --workload cfg2 --max-rails 100 --steps 30 --train > $O/rollout.log 2>&1

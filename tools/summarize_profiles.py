@@ -25,8 +25,10 @@ def counters(path):
     return acc
 
 
-for name in ("bench", "dqn", "rollout"):
-    shutil.copy(os.path.join(SRC, name, name + "_kernel_stats.csv"), os.path.join(OUT, "%s_%s_kernel_stats.csv" % (tag, name)))
+for name, stem in (("bench", "bench"), ("bench_g", "bench"), ("dqn", "dqn"), ("rollout", "rollout")):
+    src = os.path.join(SRC, name, stem + "_kernel_stats.csv")
+    if os.path.exists(src):      # bench_g: the cfg3g workload
+        shutil.copy(src, os.path.join(OUT, "%s_%s_kernel_stats.csv" % (tag, name.replace("bench_g", "bench_cfg3g"))))
 
 # MFMA utilisation of the DQN kernels: busy cycles of the matrix pipes over (elapsed GPU cycles x SIMDs)
 mf = counters(os.path.join(SRC, "dqn_mfma", "dqn_counter_collection.csv"))
