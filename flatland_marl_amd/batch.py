@@ -345,6 +345,13 @@ class ObservationBatch:
         """reset() + observations() without the dense intermediate planes.  fused_paths (default: whenever the
         tables fit the LDS) computes paths and columns straight from the chain index, without the dense distance
         maps; False takes distance maps -> shortest paths -> columns."""
+        if self.T1 > 512:
+            # the column kernels hold a path's time steps in registers (eight per lane): a longer horizon goes
+            # through the dense planes, with the same observations
+            if fused_paths:
+                raise _lib.FlmError("the fused path kernel holds at most 512 time steps")
+            self.reset(sync=sync)
+            return self.observations()
         self.build_graph(sync=sync)
         capS = self.cap_cells * 4
         chains = capS * 10 + capS // 8 + 512 <= 159 * 1024

@@ -102,12 +102,25 @@ __global__ __launch_bounds__(1024, 6) void anchor_decisions_kernel(
   __syncthreads();
   stamp(2);
 
-  // decisions per (anchor, 8 targets)
+  // decisions per (anchor, 8 targets): the labels of a move's successor for four targets are one 8-byte row
+  static_assert(FLM_TPG == 4, "the decision phase unpacks rows of four labels");
   uint16_t* bits = bits_all + (size_t)e * ldsAnch * NG8;
   for (int it = tid; it < NA * NG8; it += T) {
     const int a = it / NG8, g8 = it - a * NG8;
     const uint4 me = reinterpret_cast<const uint4*>(move_edge_all + (size_t)e * capAnch * 4)[a];
     const unsigned mv[3] = {me.x, me.y, me.z};
+    unsigned lab4[2][3][2];   // [half of the eight targets][move][word]: 0xFFFF where there is no such move or group
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+      const int g = g8 * 2 + hf;
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        uint2 v = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (mv[i] != FLM_NONE32 && g < NGRP) v = *reinterpret_cast<const uint2*>(rows + ((size_t)g * ldsAnch + (mv[i] & 0xFFFFu)) * NW);
+        lab4[hf][i][0] = v.x;
+        lab4[hf][i][1] = v.y;
+      }
+    }
     unsigned out = 0;
 #pragma unroll
     for (int t = 0; t < 8; t++) {
@@ -117,7 +130,7 @@ __global__ __launch_bounds__(1024, 6) void anchor_decisions_kernel(
 #pragma unroll
         for (int i = 0; i < 3; i++) {
           if (mv[i] == FLM_NONE32) continue;
-          const unsigned d = label_at((int)(mv[i] & 0xFFFFu), j);
+          const unsigned d = (lab4[t >> 2][i][(t >> 1) & 1] >> (16 * (t & 1))) & 0xFFFFu;
           if (d == FLM_NONE16) continue;
           const unsigned cand = d + (mv[i] >> 16);       // distance of the move's successor + 1
           if (sel == 3u || cand < best) {                 // strictly smaller wins: ties go to the earlier move
@@ -229,7 +242,40 @@ __global__ __launch_bounds__(FLM_WC_THREADS) void walk_columns_kernel(
   const int32_t* cell_idx = cell_idx_all + (size_t)e * HW;
   const int nR = min(graph_counts[e * 4 + 1], capR);
 
-  // ---- tables
+  // ---- tables.  The look-ups with a dependent second step (cell -> what stands in it, agent -> its cells) are
+  // issued first and consumed last, so that their two round trips to memory overlap the plain copies in between.
+  auto pack_rc = [&](int cell) -> unsigned {   // row << 8 | column (H, W <= 256); a cell off the grid gives 0xFFFF
+    if (cell < 0 || cell >= HW) return 0xFFFFu;
+    const int r = cell / W;
+    return (unsigned)((r << 8) | (cell - r * W));
+  };
+  const int32_t* cell_rail = cell_rail_all + (size_t)e * HW;
+  const int32_t* node_id = node_id_all + (size_t)e * HW;
+  auto id_of = [](int rl, int nd) -> unsigned {   // what stands in a cell: a rail, 0x8000 | switch, or 0xFFFF
+    return rl >= 0 ? (unsigned)rl : (nd >= 0 ? (0x8000u | (unsigned)nd) : 0xFFFFu);
+  };
+  constexpr int CU = 4;                      // cells per thread and batch
+  int c_cell[CU], c_rl[CU], c_nd[CU];
+  const int lastC = nC > 0 ? nC - 1 : 0;
+#pragma unroll
+  for (int u = 0; u < CU; u++) {
+    c_cell[u] = idx_cell_all[(size_t)e * capCells + min(u * T + tid, lastC)];
+    if (nC <= 0 || c_cell[u] < 0 || c_cell[u] >= HW) c_cell[u] = 0;
+  }
+  // agent scalars (first step): thread a of the first waves
+  const int aa = tid < A ? tid : 0;
+  const size_t ga = ea + aa;
+  const int a_c0 = start_cell_all[ga], a_t = target_cell_all[ga], a_pos = pos_cell_all[ga], a_tpc = tpc_all[ga];
+  const int a_dir = start_dir_all[ga], a_slot = tslot_all[ga], a_status = status_all[ga], a_reach = reach_all[ga];
+#pragma unroll
+  for (int u = 0; u < CU; u++) {
+    c_rl[u] = cell_rail[c_cell[u]];
+    c_nd[u] = node_id[c_cell[u]];
+  }
+  const int a_posc = (a_pos >= 0 && a_pos < HW) ? a_pos : 0;
+  const int a_tci = cell_idx[(a_t >= 0 && a_t < HW) ? a_t : 0], a_ci0 = cell_idx[(a_c0 >= 0 && a_c0 < HW) ? a_c0 : 0];
+  const int a_prl = cell_rail[a_posc], a_pnd = node_id[a_posc];
+
   for (int i = tid; i < NA * NG8; i += T) bits[i] = bits_all[(size_t)e * ldsAnch * NG8 + i];
   for (int a = tid; a < NA; a += T) {
     medge[a] = reinterpret_cast<const uint4*>(move_edge_all + (size_t)e * capAnch * 4)[a];
@@ -240,51 +286,37 @@ __global__ __launch_bounds__(FLM_WC_THREADS) void walk_columns_kernel(
     walk[s] = (uint16_t)wv;
     if ((wv & 0x8000u) && wv != FLM_NONE16 && (int)(wv & 0x7FFFu) < NA) astate[wv & 0x7FFFu] = (uint16_t)s;
   }
-  auto pack_rc = [&](int cell) -> unsigned {   // row << 8 | column (H, W <= 256); a cell off the grid gives 0xFFFF
-    if (cell < 0 || cell >= HW) return 0xFFFFu;
-    const int r = cell / W;
-    return (unsigned)((r << 8) | (cell - r * W));
-  };
-  auto cell_id = [&](int cell) -> unsigned {   // what stands in a cell: a rail, 0x8000 | switch, or 0xFFFF
-    const int rl = cell_rail_all[(size_t)e * HW + cell], nd = node_id_all[(size_t)e * HW + cell];
-    return rl >= 0 ? (unsigned)rl : (nd >= 0 ? (0x8000u | (unsigned)nd) : 0xFFFFu);
-  };
-  for (int base = 0; base < nC; base += 4 * T) {     // four independent look-up chains per thread in flight
-    int cell[4];
-    unsigned id[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int ci = base + u * T + tid;
-      cell[u] = ci < nC ? idx_cell_all[(size_t)e * capCells + ci] : 0;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) id[u] = cell_id(cell[u]);
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int ci = base + u * T + tid;
-      if (ci < nC) cinfo[ci] = pack_rc(cell[u]) | (id[u] << 16);
-    }
-  }
-  for (int a = tid; a < A; a += T) {
-    const size_t g = ea + a;
-    const int c0 = start_cell_all[g], tcell = target_cell_all[g], pos = pos_cell_all[g];
-    int tpc = tpc_all[g];
-    ag[AG_START * A + a] = c0;
-    ag[AG_DIR * A + a] = start_dir_all[g] & 3;
-    ag[AG_TCI * A + a] = (tcell >= 0 && tcell < HW) ? cell_idx[tcell] : -1;
-    ag[AG_CI0 * A + a] = (c0 >= 0 && c0 < HW) ? cell_idx[c0] : -1;
-    ag[AG_SLOT * A + a] = tslot_all[g];
-    ag[AG_POS * A + a] = (int)pack_rc(pos);
-    ag[AG_POSID * A + a] = (pos >= 0 && pos < HW) ? (int)cell_id(pos) : 0xFFFF;
-    ag[AG_TGT * A + a] = tcell;
-    ag[AG_TGTRC * A + a] = (tcell >= 0 && tcell < HW) ? (int)pack_rc(tcell) : -1;
-    ag[AG_TPC * A + a] = tpc < 1 ? 1 : tpc;
-    // status 3 (DONE_REMOVED) has no path; an unreachable target neither
-    ag[AG_LEN * A + a] = (status_all[g] != 3 ? 1 : 0) | (reach_all[g] ? 2 : 0);
-  }
   for (int r = tid; r < nR; r += T) {
     const int32_t* ei = edge_info_all + ((size_t)e * capR + r) * 5;
     rinfo[r] = pack_rail_ends(ei[0], ei[1], ei[2], ei[3]);
+  }
+#pragma unroll
+  for (int u = 0; u < CU; u++) {
+    const int ci = u * T + tid;
+    if (ci < nC) cinfo[ci] = pack_rc(c_cell[u]) | (id_of(c_rl[u], c_nd[u]) << 16);
+  }
+  for (int base = CU * T; base < nC; base += T) {     // maps with more rail cells than CU per thread
+    const int ci = base + tid;
+    if (ci < nC) {
+      const int cell = idx_cell_all[(size_t)e * capCells + ci];
+      const bool ok = cell >= 0 && cell < HW;
+      cinfo[ci] = pack_rc(cell) | ((ok ? id_of(cell_rail[cell], node_id[cell]) : 0xFFFFu) << 16);
+    }
+  }
+  if (tid < A) {
+    const int a = tid;
+    ag[AG_START * A + a] = a_c0;
+    ag[AG_DIR * A + a] = a_dir & 3;
+    ag[AG_TCI * A + a] = (a_t >= 0 && a_t < HW) ? a_tci : -1;
+    ag[AG_CI0 * A + a] = (a_c0 >= 0 && a_c0 < HW) ? a_ci0 : -1;
+    ag[AG_SLOT * A + a] = a_slot;
+    ag[AG_POS * A + a] = (int)pack_rc(a_pos);
+    ag[AG_POSID * A + a] = (a_pos >= 0 && a_pos < HW) ? (int)id_of(a_prl, a_pnd) : 0xFFFF;
+    ag[AG_TGT * A + a] = a_t;
+    ag[AG_TGTRC * A + a] = (a_t >= 0 && a_t < HW) ? (int)pack_rc(a_t) : -1;
+    ag[AG_TPC * A + a] = a_tpc < 1 ? 1 : a_tpc;
+    // status 3 (DONE_REMOVED) has no path; an unreachable target neither
+    ag[AG_LEN * A + a] = (a_status != 3 ? 1 : 0) | (a_reach ? 2 : 0);
   }
   for (int i = tid; i < A * Lr / 2; i += T) reinterpret_cast<unsigned*>(rec)[i] = 0xFFFFFFFFu;
   __syncthreads();
@@ -512,7 +544,7 @@ extern "C" int flm_paths_columns(const uint16_t* walk, const uint16_t* root, con
       !target_cell || !status || !tpc || !workspace || !path_len || !cols || !err || !counts)
     return FLM_E_ARG;
   if ((path_cell == nullptr) != (path_meta == nullptr)) return FLM_E_ARG;
-  if (E <= 0 || A <= 0 || H <= 0 || W <= 0 || H > 256 || W > 256 || capCells <= 0 || capCells * 4 > 32768 ||
+  if (E <= 0 || A <= 0 || A > FLM_WC_THREADS || H <= 0 || W <= 0 || H > 256 || W > 256 || capCells <= 0 || capCells * 4 > 32768 ||
       capAnch <= 0 || ldsAnch <= 0 || ldsAnch > capAnch || ldsAnch > 0x7FFE || ldsSlots <= 0 || (ldsSlots & 7) || capR <= 0 ||
       Rp <= 0 || Rp > 16383 || T1 <= 1 || T1 > 64 * FLM_COL_KT || max_depth < 0 || Lcap < max_depth + 1 || shift < 0)
     return FLM_E_ARG;

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(1024, 8) void graph_build_kernel(
       }
       if (is_node && id < capN) {
         // sides with a connection: where some heading may leave to, and where it comes in from
-        const unsigned code = grid_g[cell];
+        const unsigned code = LDS_GRID ? (unsigned)l_code[cell] : (unsigned)grid_g[cell];   // (this thread stored it above)
         unsigned mask = 0;
         if (code == 0x8421u) {
           mask = 0xF;

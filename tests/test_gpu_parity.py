@@ -174,6 +174,26 @@ def test_long_horizon_uses_sequential_formulation():
     assert np.array_equal(b.maps_numpy(0), maps)
 
 
+def test_long_horizon_observations_fall_back_to_dense_planes():
+    """reset_fused at depth 600: the column kernels stop at 512 time steps, the observations come from the dense
+    planes instead and are the checker's."""
+    from oracle import oracle as orc
+    depth = 600
+    fx = load_env("Test_1_Level_0")
+    b = _batch(fx, depth)
+    obs = b.reset_fused()
+    env = orc.OracleEnv(fx, depth)
+    maps, _, errs = env.get_many()
+    assert [ERR.get(x, 0) for x in errs] == list(b.agent_err[0].cpu().numpy())
+    R, T1, A = env.g.R, depth + 1, b.A
+    got = obs[0, :, :, :b.Rp * T1].cpu().numpy().reshape(A, 3, b.Rp, T1)
+    assert np.array_equal(got[:, 0, :R].view(np.int8), maps)
+    tot_p, tot_n = (maps > 0).sum(axis=0), (maps < 0).sum(axis=0)
+    for a in range(A):
+        assert np.array_equal(got[a, 1, :R], tot_p - (maps[a] > 0))
+        assert np.array_equal(got[a, 2, :R], tot_n - (maps[a] < 0))
+
+
 @pytest.mark.parametrize("name", ["Test_1_Level_0", "Test_5_Level_1", "Test_8_Level_0"])
 def test_breadth_first_fallback_equals_chain_compression(name):
     """The two distance methods give the same value for every valid state of every used row."""
