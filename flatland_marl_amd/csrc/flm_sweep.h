@@ -191,11 +191,12 @@ __device__ __forceinline__ int anchor_sweep_regs(unsigned* rows, const uint4* __
   return round;
 }
 
-// Picks the register-resident sweep when a lane's share of the anchors fits it.
-template <int NW>
+// Picks the register-resident sweep when a lane's share of the anchors fits it (PM anchors per lane: what the
+// kernel's register budget holds).
+template <int NW, int PM = 10>
 __device__ __forceinline__ int anchor_sweep(unsigned* rows, const uint4* __restrict__ ed, int NA, int lane) {
   const int P = (NA + 63) >> 6;
-  if (P <= 10) return anchor_sweep_regs<NW, 10>(rows, ed, NA, lane);
+  if (P <= PM) return anchor_sweep_regs<NW, PM>(rows, ed, NA, lane);
   return anchor_sweep_chunks<NW>(rows, ed, NA, lane);
 }
 

@@ -37,7 +37,11 @@ __host__ __device__ inline unsigned decisions_lds_bytes(int ldsAnch, int ldsSlot
   return align16(16u * ldsAnch) + align16(2u * (unsigned)ldsAnch * (unsigned)ldsSlots);
 }
 
-__global__ __launch_bounds__(1024, 6) void anchor_decisions_kernel(
+// PM: anchors per lane the sweep keeps in registers; WPS: waves per SIMD the register budget is cut for.  Tables up
+// to 80 KB leave room for two workgroups per CU (PM 10 in 80 registers); larger ones run alone on their CU and
+// get 128 registers, enough for 13 anchors per lane (832 anchors).
+template <int PM, int WPS>
+__global__ __launch_bounds__(1024, WPS) void anchor_decisions_kernel(
     const uint16_t* __restrict__ root_all, const uint32_t* __restrict__ edges_all, const uint32_t* __restrict__ move_edge_all,
     const int32_t* __restrict__ n_anchor_all, const int32_t* __restrict__ cell_idx_all,
     const int32_t* __restrict__ tslot_all, const int32_t* __restrict__ n_slots_all, const int32_t* __restrict__ slot_target_all,
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(1024, 6) void anchor_decisions_kernel(
   __syncthreads();
   stamp(1);
   for (int g = wave; g < NGRP; g += T / 64) {
-    const int rounds = anchor_sweep<NW>(rows + (size_t)g * ldsAnch * NW, ed, NA, lane);
+    const int rounds = anchor_sweep<NW, PM>(rows + (size_t)g * ldsAnch * NW, ed, NA, lane);
     if (stamps && g == 0 && lane == 0) stamps[(size_t)blockIdx.x * 16 + 15] = (unsigned long long)rounds;
   }
   __syncthreads();
@@ -557,12 +561,18 @@ extern "C" int flm_paths_columns(const uint16_t* walk, const uint16_t* root, con
   // one wave per group of four targets (at least four waves for the set-up loops, at most sixteen)
   int waves = (ldsSlots + FLM_TPG - 1) / FLM_TPG;
   waves = waves < 4 ? 4 : (waves > 16 ? 16 : waves);
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(flm::anchor_decisions_kernel),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess)
-    return FLM_E_LAUNCH;
-  hipLaunchKernelGGL(flm::anchor_decisions_kernel, dim3(E), dim3(waves * 64), lds1, stream, root, edges, move_edge, n_anchor,
-                     cell_idx, tslot, n_slots, slot_target, start_cell, start_dir, A, H * W, capCells, capAnch, ldsAnch,
-                     ldsSlots, bits, reach, counts, g_flm_stamps);
+  const bool alone = lds1 > 80 * 1024;   // one workgroup per CU anyway: a larger register budget costs nothing
+  const void* k1 = alone ? reinterpret_cast<const void*>(flm::anchor_decisions_kernel<13, 4>)
+                         : reinterpret_cast<const void*>(flm::anchor_decisions_kernel<10, 6>);
+  if (hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess) return FLM_E_LAUNCH;
+  if (alone)
+    hipLaunchKernelGGL((flm::anchor_decisions_kernel<13, 4>), dim3(E), dim3(waves * 64), lds1, stream, root, edges, move_edge,
+                       n_anchor, cell_idx, tslot, n_slots, slot_target, start_cell, start_dir, A, H * W, capCells, capAnch,
+                       ldsAnch, ldsSlots, bits, reach, counts, g_flm_stamps);
+  else
+    hipLaunchKernelGGL((flm::anchor_decisions_kernel<10, 6>), dim3(E), dim3(waves * 64), lds1, stream, root, edges, move_edge,
+                       n_anchor, cell_idx, tslot, n_slots, slot_target, start_cell, start_dir, A, H * W, capCells, capAnch,
+                       ldsAnch, ldsSlots, bits, reach, counts, g_flm_stamps);
   FLM_CHECK_LAUNCH();
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(flm::walk_columns_kernel),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total) != hipSuccess)

@@ -55,8 +55,44 @@ __device__ Walk walk_rail(const uint16_t* grid, const NodeT* node_id, int H, int
   return w;
 }
 
-// LDS_GRID: the transition codes and the node numbers of the environment are staged in LDS (2 + 2 bytes per
-// cell), so that the rail walks, chains of dependent look-ups, run at LDS latency.
+// The same walk over one 32-bit word per cell staged in LDS: transition code | switch number << 16 (0xFFF = none)
+// | border << 28 (bit d: heading d leaves the grid from here).  One look-up per step, no row/column bookkeeping.
+#define FLM_WORD_NONODE 0xFFFu
+template <bool EMIT>
+__device__ Walk walk_rail_words(const unsigned* words, int H, int W, int cell, int dir, int32_t* out, int out_cap,
+                                int32_t* cell_rail, int rail) {
+  Walk w;
+  w.end_port = -1;
+  w.len = 0;
+  unsigned word = words[cell];
+  const int cap_steps = 4 * H * W;  // the sequential definition does not terminate on a cycle of plain cells
+  for (int step = 0; step < cap_steps; step++) {
+    if ((word >> (28 + dir)) & 1u) return w;  // leaves the grid: no edge
+    const int ncell = cell + (dir == 0 ? -W : (dir == 1 ? 1 : (dir == 2 ? W : -1)));
+    const unsigned nw = words[ncell];
+    const unsigned id2 = (nw >> 16) & 0xFFFu;
+    if (id2 != FLM_WORD_NONODE) {
+      w.end_port = (int)id2 * 4 + ((dir + 2) & 3);
+      return w;
+    }
+    if (EMIT) {
+      if (w.len < out_cap) out[w.len] = ncell * 4 + dir;
+      atomicMin(reinterpret_cast<unsigned*>(cell_rail) + ncell, (unsigned)rail);
+    }
+    w.len++;
+    // next heading: first allowed exit other than the side we came from; North when there is none (whether it
+    // leaves the grid is seen at the top of the next step)
+    const int nib = nibble(nw & 0xFFFFu, dir) & ~(1 << (3 - ((dir + 2) & 3)));
+    dir = nib ? (3 - (31 - __clz(nib))) : 0;
+    cell = ncell;
+    word = nw;
+  }
+  w.end_port = -1;
+  return w;
+}
+
+// LDS_GRID: the transition codes, node numbers and border flags of the environment are staged in LDS (one 32-bit
+// word per cell), so that the rail walks, chains of dependent look-ups, run at LDS latency.
 template <bool LDS_GRID>
 __global__ __launch_bounds__(1024, 8) void graph_build_kernel(
     const uint16_t* __restrict__ grid_all, int H, int W, int capN, int capR, int capC, int32_t* __restrict__ node_id_all,
@@ -85,9 +121,8 @@ __global__ __launch_bounds__(1024, 8) void graph_build_kernel(
   int* p_len = p_end + 4 * capN;      // [4*capN]
   int* p_first = p_len + 4 * capN;    // [4*capN]
   int* conn = p_first + 4 * capN;     // [capN] connection mask per node
-  uint16_t* l_code = reinterpret_cast<uint16_t*>(conn + capN);   // [HW] when LDS_GRID
-  int16_t* l_node = reinterpret_cast<int16_t*>(l_code + HW);     // [HW] when LDS_GRID
-  const uint16_t* grid = LDS_GRID ? l_code : grid_g;
+  unsigned* words = reinterpret_cast<unsigned*>(conn + capN);     // [HW] when LDS_GRID
+  const uint16_t* grid = grid_g;
   const int tid = threadIdx.x, T = blockDim.x;
   int err = 0;
 
@@ -104,7 +139,11 @@ __global__ __launch_bounds__(1024, 8) void graph_build_kernel(
       const int cell = base0 + k * T + tid;
       if (cell < HW) {
         const unsigned code = codes[k];
-        if (LDS_GRID) l_code[cell] = (uint16_t)code;
+        if (LDS_GRID) {
+          const int r = cell / W, c = cell - r * W;
+          const unsigned border = (r == 0 ? 1u : 0u) | (c == W - 1 ? 2u : 0u) | (r == H - 1 ? 4u : 0u) | (c == 0 ? 8u : 0u);
+          words[cell] = code | (border << 28) | (FLM_WORD_NONODE << 16);
+        }
         // a switch: some heading has a choice of exits; the diamond crossing counts as one as well
         const bool is_node = code == 0x8421u || __popc(code & 0xFu) > 1 || __popc(code & 0xF0u) > 1 ||
                              __popc(code & 0xF00u) > 1 || __popc(code & 0xF000u) > 1;
@@ -120,11 +159,11 @@ __global__ __launch_bounds__(1024, 8) void graph_build_kernel(
       const int id = n_nodes + multi_flag_rank(node_bits, k, mscan);
       if (cell < HW) {
         node_id[cell] = (is_node && id < capN) ? id : -1;
-        if (LDS_GRID) l_node[cell] = (int16_t)((is_node && id < capN) ? id : -1);
+        if (LDS_GRID && is_node && id < capN) words[cell] = (words[cell] & 0xF000FFFFu) | ((unsigned)id << 16);
       }
       if (is_node && id < capN) {
         // sides with a connection: where some heading may leave to, and where it comes in from
-        const unsigned code = LDS_GRID ? (unsigned)l_code[cell] : (unsigned)grid_g[cell];   // (this thread stored it above)
+        const unsigned code = LDS_GRID ? (words[cell] & 0xFFFFu) : (unsigned)grid_g[cell];   // (this thread stored it above)
         unsigned mask = 0;
         if (code == 0x8421u) {
           mask = 0xF;
@@ -159,7 +198,7 @@ __global__ __launch_bounds__(1024, 8) void graph_build_kernel(
     p_len[p] = 0;
     int n = p >> 2, cp = p & 3;
     if ((conn[n] >> cp) & 1) {
-      Walk w = LDS_GRID ? walk_rail<false>(grid, l_node, H, W, node_cell[n], cp, nullptr, 0, nullptr, 0)
+      Walk w = LDS_GRID ? walk_rail_words<false>(words, H, W, node_cell[n], cp, nullptr, 0, nullptr, 0)
                         : walk_rail<false>(grid, node_id, H, W, node_cell[n], cp, nullptr, 0, nullptr, 0);
       p_end[p] = w.end_port;
       p_len[p] = w.len;
@@ -203,7 +242,7 @@ __global__ __launch_bounds__(1024, 8) void graph_build_kernel(
       edge_cell_off[id] = off;
       int room = capC - off;
       if (LDS_GRID)
-        walk_rail<true>(grid, l_node, H, W, node_cell[p >> 2], p & 3, edge_cells + off, room < 0 ? 0 : room, cell_rail, id);
+        walk_rail_words<true>(words, H, W, node_cell[p >> 2], p & 3, edge_cells + off, room < 0 ? 0 : room, cell_rail, id);
       else
         walk_rail<true>(grid, node_id, H, W, node_cell[p >> 2], p & 3, edge_cells + off, room < 0 ? 0 : room, cell_rail, id);
     }
