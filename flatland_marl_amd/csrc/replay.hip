@@ -27,8 +27,8 @@ __global__ __launch_bounds__(1024) void replay_sample_kernel(int size, int batch
                                                              int32_t* __restrict__ idx_out) {
   __shared__ unsigned hist[256];
   __shared__ unsigned s_prefix, s_need;
-  __shared__ int scratch[16];
-  const int tid = threadIdx.x;
+  __shared__ int scratch[16 * 8 + 1];
+  const int tid = threadIdx.x, lane = tid & 63;
   // key of rank `batch` (1-based): narrow the prefix eight bits at a time
   unsigned prefix = 0, need = (unsigned)batch;   // `need` = rank still to find among the keys that match the prefix
   for (int pass = 0; pass < 4; pass++) {
@@ -40,36 +40,58 @@ __global__ __launch_bounds__(1024) void replay_sample_kernel(int size, int batch
       if (pass == 0 || (k >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(k >> shift) & 255u], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      unsigned acc = 0, b = 0;
-      for (; b < 256; b++) {
-        if (acc + hist[b] >= need) break;
-        acc += hist[b];
+    if (tid < 64) {
+      // the bin in which the running count reaches `need`: every lane sums four bins, the wave scans the sums
+      const unsigned h0 = hist[lane * 4], h1 = hist[lane * 4 + 1], h2 = hist[lane * 4 + 2], h3 = hist[lane * 4 + 3];
+      const unsigned sum = h0 + h1 + h2 + h3;
+      unsigned inc = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
       }
-      s_prefix = prefix | (b << shift);
-      s_need = need - acc;
+      const unsigned before = inc - sum;           // keys in the bins below this lane's four
+      if (before < need && inc >= need) {           // exactly one lane: counts are non-negative and the total >= need
+        unsigned acc = before, b = (unsigned)lane * 4;
+        if (acc + h0 < need) { acc += h0; b++;
+          if (acc + h1 < need) { acc += h1; b++;
+            if (acc + h2 < need) { acc += h2; b++; } } }
+        s_prefix = prefix | (b << shift);
+        s_need = need - acc;
+      }
     }
     __syncthreads();
     prefix = s_prefix;
     need = s_need;
-    __syncthreads();
   }
-  // every key below `prefix` is in; of the keys equal to it, the first `need` in index order
+  // every key below `prefix` is in; of the keys equal to it, the first `need` in index order.  Entries are ranked
+  // eight strided passes at a time (multi_flag_counts), ties first, then the chosen ones.
   int n_out = 0, n_tie = 0;
-  for (int base = 0; base < size; base += 1024) {
-    const int i = base + tid;
-    uint32_t k = 0xFFFFFFFFu;
-    bool below = false, tie = false;
-    if (i < size) {
-      k = replay_key(seed, draw, (uint32_t)i);
-      below = k < prefix;
-      tie = k == prefix;
+  constexpr int KB = 8;
+  for (int base0 = 0; base0 < size; base0 += KB * 1024) {
+    unsigned below_bits = 0, tie_bits = 0;
+#pragma unroll
+    for (int k = 0; k < KB; k++) {
+      const int i = base0 + k * 1024 + tid;
+      if (i < size) {
+        const uint32_t key = replay_key(seed, draw, (uint32_t)i);
+        if (key < prefix) below_bits |= 1u << k;
+        if (key == prefix) tie_bits |= 1u << k;
+      }
     }
-    int tot_t, tot_o;
-    const int rank_t = n_tie + block_flag_scan(tie, scratch, &tot_t);
-    const bool take = below || (tie && rank_t < (int)need);
-    const int pos = n_out + block_flag_scan(take, scratch, &tot_o);
-    if (take && pos < batch) idx_out[pos] = i;
+    const int tot_t = multi_flag_counts<KB>(tie_bits, scratch);
+    unsigned take_bits = below_bits;
+#pragma unroll
+    for (int k = 0; k < KB; k++) {
+      const int rank_t = n_tie + multi_flag_rank(tie_bits, k, scratch);
+      if (((tie_bits >> k) & 1u) && rank_t < (int)need) take_bits |= 1u << k;
+    }
+    const int tot_o = multi_flag_counts<KB>(take_bits, scratch);
+#pragma unroll
+    for (int k = 0; k < KB; k++) {
+      const int pos = n_out + multi_flag_rank(take_bits, k, scratch);
+      if (((take_bits >> k) & 1u) && pos < batch) idx_out[pos] = base0 + k * 1024 + tid;
+    }
     n_tie += tot_t;
     n_out += tot_o;
   }

@@ -11,9 +11,13 @@ namespace flm {
 // leaf; then every lane completes one leaf by a greedy descent of at most max_depth moves, so the walks of
 // a request run side by side; last, leaves whose descent found no way are squeezed out in order.
 // More than cap_alt leaves is FLM_AGENT_OVERFLOW.
+// STAGE: one request per wave (G = 64) and the environment's successor table (2 bytes per state) copied into LDS
+// first, so that the forced steps of the descents - most of a path, one dependent look-up each - run at LDS
+// latency; the kernel is bound by the latency of one descent, not by throughput.
 #define FLM_ALT_STACK 32
 #define FLM_ALT_FRAME_INTS (2 * (FLM_ALT_STACK + 2) + 4 * FLM_ALT_STACK + 6 * FLM_ALT_STACK)   // per request
 
+template <bool STAGE>
 __global__ __launch_bounds__(64) void altpaths_kernel(
     const uint16_t* __restrict__ grid_all, const int32_t* __restrict__ cell_idx_all,
     const uint16_t* __restrict__ dist_all, const uint16_t* __restrict__ succ_all,
@@ -24,7 +28,7 @@ __global__ __launch_bounds__(64) void altpaths_kernel(
     int G, int32_t* __restrict__ alt_count, int32_t* __restrict__ alt_len, int32_t* __restrict__ alt_cell,
     uint32_t* __restrict__ alt_meta, int32_t* __restrict__ err_out) {
   __shared__ int s_cell[64], s_h[64], s_base[64], s_res[64], s_n[64], s_err[64];
-  extern __shared__ int alt_frames[];     // [64 / G][FLM_ALT_FRAME_INTS]
+  extern __shared__ __attribute__((aligned(16))) int alt_frames[];     // [64 / G][FLM_ALT_FRAME_INTS], then the staged table
   const int lane = threadIdx.x, grp = lane / G, j = lane - grp * G;
   const int g = blockIdx.x * (64 / G) + grp;
   const bool live = g < n_req;
@@ -37,6 +41,14 @@ __global__ __launch_bounds__(64) void altpaths_kernel(
   const uint16_t* dist = dist_all + ((size_t)e * A + tslot[ga]) * capCells * 4;
   const uint16_t* succ = succ_all ? succ_all + (size_t)e * capCells * 4 : nullptr;
   const uint16_t* choice = succ_all && choice_all ? choice_all + (size_t)e * capCells * 16 : nullptr;
+  uint16_t* succ_lds = reinterpret_cast<uint16_t*>(alt_frames + FLM_ALT_FRAME_INTS);   // STAGE: [capCells * 4]
+  if (STAGE) {
+    // (G = 64: the whole wave serves one request, e is the same for every lane)
+    const uint4* src = reinterpret_cast<const uint4*>(succ);
+    uint4* dst = reinterpret_cast<uint4*>(succ_lds);
+    for (int i = lane; i < capCells / 2; i += 64) dst[i] = src[i];     // capCells * 8 bytes, 16 per copy
+    if ((capCells & 1) && lane < 4) succ_lds[(capCells - 1) * 4 + lane] = succ[(capCells - 1) * 4 + lane];
+  }
   const int tcell = target_cell[ga];
   int32_t* out_len = alt_len + (size_t)g * cap_alt;
   int32_t* slot_cell = alt_cell + (size_t)g * cap_alt * Lcap;
@@ -129,8 +141,9 @@ __global__ __launch_bounds__(64) void altpaths_kernel(
       if (start == -1) {
         res = base;
       } else if (start >= 0) {
-        const int n = greedy_path(grid, cell_idx, dist, succ, choice, H, W, start, s_h[lane], tcell, max_depth,
-                                  slot_cell + (size_t)j * Lcap + base, slot_meta + (size_t)j * Lcap + base, Lcap - base);
+        const int n = greedy_path(grid, cell_idx, dist, STAGE ? succ_lds : succ, choice, H, W, start, s_h[lane], tcell,
+                                  max_depth, slot_cell + (size_t)j * Lcap + base, slot_meta + (size_t)j * Lcap + base,
+                                  Lcap - base);
         if (n >= 0) res = base + n > Lcap ? -2 : base + n;
       }
       s_res[lane] = res;
@@ -359,14 +372,25 @@ extern "C" int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const
     return FLM_E_ARG;
   int G = 1;                              // lanes per request
   while (G < cap_alt) G *= 2;
-  const int per_block = 64 / G;
-  const size_t lds = (size_t)per_block * FLM_ALT_FRAME_INTS * sizeof(int);
-  if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(flm::altpaths_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return FLM_E_LAUNCH;
-  hipLaunchKernelGGL(flm::altpaths_kernel, dim3((n_req + per_block - 1) / per_block), dim3(64), lds, (hipStream_t)stream,
-                     grid, cell_idx, dist, succ, choice, tslot, node_id, req_agent, n_req, pos_cell, direction, target_cell, A, H, W,
-                     capCells, max_depth, cap_alt, Lcap, G, alt_count, alt_len, alt_cell, alt_meta, err);
+  // one request per wave with the successor table in LDS when there is one, it is 16-byte aligned per environment
+  // and it fits beside the frames
+  const size_t staged_lds = (size_t)FLM_ALT_FRAME_INTS * sizeof(int) + (size_t)capCells * 8 + 16;
+  const bool stage = succ && choice && (((uintptr_t)succ | ((size_t)capCells * 8)) & 15) == 0 && staged_lds <= 64 * 1024;
+  if (stage) {
+    hipLaunchKernelGGL(flm::altpaths_kernel<true>, dim3(n_req), dim3(64), staged_lds, (hipStream_t)stream, grid, cell_idx,
+                       dist, succ, choice, tslot, node_id, req_agent, n_req, pos_cell, direction, target_cell, A, H, W,
+                       capCells, max_depth, cap_alt, Lcap, 64, alt_count, alt_len, alt_cell, alt_meta, err);
+  } else {
+    const int per_block = 64 / G;
+    const size_t lds = (size_t)per_block * FLM_ALT_FRAME_INTS * sizeof(int);
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(flm::altpaths_kernel<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return FLM_E_LAUNCH;
+    hipLaunchKernelGGL(flm::altpaths_kernel<false>, dim3((n_req + per_block - 1) / per_block), dim3(64), lds,
+                       (hipStream_t)stream, grid, cell_idx, dist, succ, choice, tslot, node_id, req_agent, n_req, pos_cell,
+                       direction, target_cell, A, H, W, capCells, max_depth, cap_alt, Lcap, G, alt_count, alt_len, alt_cell,
+                       alt_meta, err);
+  }
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }
