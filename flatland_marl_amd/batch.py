@@ -166,7 +166,7 @@ class ObservationBatch:
         if getattr(self, "dist", None) is None:
             self.dist = torch.empty((E, A, capS), dtype=torch.int16, device=dev)
         if method is None:
-            method = "chains" if capS * 10 + capS // 8 + 512 <= 159 * 1024 else "bfs"
+            method = "chains" if capS * 6 + capS // 8 + 1024 <= 159 * 1024 else "bfs"
         if method == "bfs":
             self._succ_valid = False
             if self.pred is None:
@@ -354,7 +354,7 @@ class ObservationBatch:
             return self.observations()
         self.build_graph(sync=sync)
         capS = self.cap_cells * 4
-        chains = capS * 10 + capS // 8 + 512 <= 159 * 1024
+        chains = capS * 6 + capS // 8 + 1024 <= 159 * 1024
         if fused_paths is not False and chains:
             self.chain_index()
             if self.fused_fits():

@@ -44,11 +44,12 @@ __global__ __launch_bounds__(1024, 8) void chain_index_kernel(
   // of the H*W grid cells), otherwise by scanning the grid
   const int32_t* idx_cell = idx_cell_all ? idx_cell_all + (size_t)e * capCells : nullptr;
   const int n_visit = idx_cell ? S / 4 : HW;
-  uint16_t* jmp0 = reinterpret_cast<uint16_t*>(smem);   // [capS]
-  uint16_t* jmp1 = jmp0 + capS;
-  uint16_t* stp0 = jmp1 + capS;
-  uint16_t* stp1 = stp0 + capS;
-  uint16_t* aidx = stp1 + capS;                          // [capS] anchor number or NONE
+  // per state one word: the state its forced moves have been followed to so far | the number of moves << 16.
+  // Pointer doubling updates the words in place: whatever mixture of old and new words a thread reads, "d moves
+  // from s lead to j" stays a true statement, and the fixed point (every pointer names an anchor or a state
+  // without moves) does not depend on the order.
+  unsigned* jw = reinterpret_cast<unsigned*>(smem);       // [capS]
+  uint16_t* aidx = reinterpret_cast<uint16_t*>(jw + capS);  // [capS] anchor number or NONE
   unsigned* flags = reinterpret_cast<unsigned*>(aidx + capS + (capS & 1));  // [capS/32+1] anchor bits
   int* scratch = reinterpret_cast<int*>(flags + (capS + 31) / 32 + 1);       // 16 * 8 + 1 ints (multi_flag_counts)
   uint16_t* root = root_all + (size_t)e * capS;
@@ -124,13 +125,8 @@ __global__ __launch_bounds__(1024, 8) void chain_index_kernel(
         *reinterpret_cast<uint2*>(choice_all + ((size_t)e * capS + s) * 4) =
             make_uint2(slot[0] | (slot[1] << 16), slot[2] | (single << 16));
       }
-      if (anchor || deg == 0) {
-        jmp0[s] = (uint16_t)s;   // fixed point: anchors end a chain, dead states lead nowhere
-        stp0[s] = 0;
-      } else {
-        jmp0[s] = (uint16_t)nxt;
-        stp0[s] = 1;
-      }
+      // fixed point: anchors end a chain, dead states lead nowhere; the others take their one move
+      jw[s] = (anchor || deg == 0) ? (unsigned)s : ((unsigned)nxt | (1u << 16));
     }
   };
   // The first passes keep what they looked up in registers for the edge phase below (same thread, same cell): the
@@ -188,22 +184,21 @@ __global__ __launch_bounds__(1024, 8) void chain_index_kernel(
     for (int s = tid; s < S; s += T) succ[s] = aidx[s];
   }
   // pointer doubling
-  uint16_t* ja = jmp0; uint16_t* jb = jmp1; uint16_t* sa = stp0; uint16_t* sb = stp1;
   // (a round in which every pointer already names a fixed point changes nothing: the loop ends there, after
   // about log2 of the longest run of forced moves; only anchor-free loops keep it going to log2 S)
   for (int span = 1; span < S; span <<= 1) {
     int more = 0;
     for (int s = tid; s < S; s += T) {
-      const int j = ja[s];
-      const int jj = ja[j];
-      unsigned st = (unsigned)sa[s] + (unsigned)sa[j];
+      const unsigned w = jw[s];
+      const unsigned j = w & 0xFFFFu;
+      const unsigned wj = jw[j];
+      const unsigned jj = wj & 0xFFFFu;
+      unsigned st = (w >> 16) + (wj >> 16);
+      if (st > 0xFFFEu) st = 0xFFFEu;
       more |= jj != j;
-      jb[s] = (uint16_t)jj;
-      sb[s] = (uint16_t)(st > 0xFFFEu ? 0xFFFEu : st);
+      jw[s] = jj | (st << 16);
     }
     more = __syncthreads_or(more);
-    uint16_t* t = ja; ja = jb; jb = t;
-    t = sa; sa = sb; sb = t;
     if (!more) break;
   }
   stamp(2);
@@ -235,11 +230,11 @@ __global__ __launch_bounds__(1024, 8) void chain_index_kernel(
   }
   // per state: anchor reached and steps to it
   for (int s = tid; s < S; s += T) {
-    const int j = ja[s];
+    const int j = (int)(jw[s] & 0xFFFFu);
     const unsigned aj = aidx[j];
     const bool ok = aj != FLM_NONE16 && aj < (unsigned)capAnch;
     root[s] = ok ? (uint16_t)aj : (uint16_t)FLM_NONE16;
-    steps[s] = ok ? sa[s] : 0;
+    steps[s] = ok ? (uint16_t)(jw[s] >> 16) : 0;
     if (walk_all) {
       // what a path walk does in state s: a forced state names its successor, an anchor its own number
       // (bit 15 set), a state without moves 0xFFFF.  The successor is the value this thread stored to succ above.
@@ -267,9 +262,10 @@ __global__ __launch_bounds__(1024, 8) void chain_index_kernel(
       for (int n = 0; n < 4; n++) {
         if (!has_exit(nib, n) || nbr[n] < 0) continue;
         const int ns = nbr[n] * 4 + n;
-        const unsigned aj = aidx[ja[ns]];
+        const unsigned wn = jw[ns];
+        const unsigned aj = aidx[wn & 0xFFFFu];
         if (aj == FLM_NONE16 || aj >= (unsigned)capAnch) continue;   // leads to a dead end or an endless loop
-        via[n] = aj | ((1u + sa[ns]) << 16);
+        via[n] = aj | ((1u + (wn >> 16)) << 16);
         if (k == 0) o0 = via[n];
         else if (k == 1) o1 = via[n];
         else if (k == 2) o2 = via[n];
@@ -423,7 +419,7 @@ extern "C" int flm_chain_index(const uint16_t* grid, const int32_t* cell_idx, co
   if (E <= 0 || A <= 0 || H <= 0 || W <= 0 || capCells <= 0 || capCells * 4 >= 65535 || capAnch <= 0 || capAnch > 0xFFF0)
     return FLM_E_ARG;
   const size_t capS = (size_t)capCells * 4;
-  size_t lds = capS * 2 * 5 + 16 + ((capS + 31) / 32 + 1) * 4 + 4 * (16 * 8 + 1) + 64;
+  size_t lds = capS * 6 + 16 + ((capS + 31) / 32 + 1) * 4 + 4 * (16 * 8 + 1) + 64;
   if (lds > 160 * 1024 - 512) return FLM_E_ARG;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(flm::chain_index_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds) != hipSuccess)
