@@ -787,7 +787,9 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void conv_u8_kernel(
   // Software pipeline over this wave's tiles: while tile t is multiplied its successor's bytes are in flight;
   // they are written to LDS right after the products, and only then are the outputs of tile t stored, so that
   // those stores drain during the next tile's products instead of in front of a wait.
-  unsigned t = __builtin_amdgcn_readfirstlane(blockIdx.x * NWAVE + wave);
+  // (tile t goes to workgroup t % gridDim.x: when the tiles are not a multiple of the waves, the waves with one
+  // tile more are spread over all CUs instead of filling the first few)
+  unsigned t = __builtin_amdgcn_readfirstlane(wave * gridDim.x + blockIdx.x);
   unsigned cur_rows = 0, cur_drel = 0;
   long cur_out0 = 0;
   int cur_os = 0;
