@@ -455,15 +455,26 @@ __global__ __launch_bounds__(256) void observations_req_columns_kernel(const int
   const int e = ga / A, a = ga - e * A;
   const int p0 = blockIdx.x * tile_bytes;
   const int tw = tile_bytes / 4;
-  for (int i = tid; i < 3 * tw; i += 256) req_tile[i] = 0;
+  for (int i = tid; i < 3 * tw / 4; i += 256) reinterpret_cast<uint4*>(req_tile)[i] = make_uint4(0u, 0u, 0u, 0u);   // tile_bytes % 16 == 0
   __syncthreads();
   const int16_t* env = cols + (size_t)e * A * T1;
-  for (int o = 0; o < A; o++) {
-    if (o == a) continue;
-    for (int t = tid; t < T1; t += 256) {
-      const int c = env[o * T1 + t];
-      if (c < 0) continue;
-      const int p = (c >> 1) * T1 + t - p0;
+  // the environment's A*T1 column entries, eight per thread in flight at once (no load is conditional)
+  const int n_ent = A * T1;
+  const float inv_T1 = 1.0f / (float)T1;
+  for (int base = 0; base < n_ent; base += 8 * 256) {
+    int cv[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) cv[u] = env[min(base + u * 256 + tid, n_ent - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = base + u * 256 + tid;
+      const int c = cv[u];
+      if (i >= n_ent || c < 0) continue;
+      int o = (int)((float)i * inv_T1);          // i / T1, corrected below (i < 2^24: the estimate is off by at most one)
+      if (o * T1 > i) o--;
+      else if ((o + 1) * T1 <= i) o++;
+      if (o == a) continue;
+      const int p = (c >> 1) * T1 + (i - o * T1) - p0;
       if (p >= 0 && p < tile_bytes) atomicAdd(&req_tile[((c & 1) ? 1 : 2) * tw + (p >> 2)], 1u << ((p & 3) * 8));
     }
   }

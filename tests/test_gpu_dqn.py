@@ -163,6 +163,27 @@ def test_gradients_elementwise_vs_torch(B, H3, T1):
         agent.optimizer.v.copy_(torch.cat([st[i]["exp_avg_sq"].reshape(-1) for i in range(len(st))]))
 
 
+@pytest.mark.parametrize("H3,T1", [(21, 37), (300, 151), (12, 301)])
+def test_small_batch_forward_vs_torch(H3, T1):
+    """The act path (batches of 1..8: the four-rows-per-workgroup convolution and the weight-streaming first dense
+    layer) against plain PyTorch fp32, for every batch size, with rows that straddle samples (H3 not a multiple of 4)."""
+    from flatland_marl_amd.agent import DQNAgent
+    from tests.torch_ref_dqn import TorchDuelingDQN
+    torch.manual_seed(H3)
+    args = argparse.Namespace(prediction_depth=T1 - 1, lr=0.001, buffer_size=10, batch_size=8, update_every=1,
+                              gamma=0.9, tau=0.05)
+    agent = DQNAgent(args, action_space=2, bitmap_height=H3)
+    ref = TorchDuelingDQN(T1, H3)
+    ref.load_state_dict(agent.qnetwork_local.state_dict())
+    g = torch.Generator().manual_seed(H3 + T1)
+    for B in range(1, 10):                      # 9: the first batch size beyond the act path
+        x = torch.randint(-1, 6, (B, 1, H3, T1), generator=g).float()
+        want = ref(x).detach().numpy()
+        got = agent.qnetwork_local(x).cpu().numpy()
+        assert got.shape == (B, 2)
+        assert close(got, want), B
+
+
 @pytest.mark.parametrize("B,Rp,T1,pad", [(5, 10, 21, 0), (300, 7, 151, 3), (33, 4, 301, 1), (700, 100, 151, 0)])
 def test_forward_from_uint8_observations_vs_torch(B, Rp, T1, pad):
     """The byte-input forward (convolution reads int8 / uint8 planes) against plain PyTorch fp32 on the same values;
