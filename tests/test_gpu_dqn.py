@@ -211,15 +211,17 @@ def test_forward_from_uint8_observations_vs_torch(B, Rp, T1, pad):
     assert close(got, want)
 
 
-def test_learn_from_uint8_observations_matches_float_learn():
+@pytest.mark.parametrize("Rp,T1,B,ps", [(37, 61, 96, 2304), (11, 151, 70, 1664 + 16), (5, 255, 33, 1280), (1, 100, 9, 112)])
+def test_learn_from_uint8_observations_matches_float_learn(Rp, T1, B, ps):
     """flm_dqn_learn_grads_u8 (bytes in, as the device replay memory stores them) against flm_dqn_learn_grads on
-    the float expansion of the same observations: loss and every gradient within 1e-5 relative."""
+    the float expansion of the same observations: loss and every gradient within 1e-5 relative.  Horizons on both
+    sides of the sizes the convolution's weight-gradient kernel takes (97..256 time steps), plane strides that are
+    and are not multiples of 256, a single rail per plane."""
     import types
     import torch
     from flatland_marl_amd.agent import DQNAgent
     from flatland_marl_amd._lib import call, ptr, query
-    Rp, T1, B = 37, 61, 96
-    ps = 2304                                                  # > Rp*T1 = 2257, a multiple of 256
+    assert ps >= Rp * T1 and ps % 16 == 0
     args = types.SimpleNamespace(prediction_depth=T1 - 1, lr=5e-5, buffer_size=10, batch_size=B, update_every=10,
                                  gamma=0.99, tau=1e-3)
     torch.manual_seed(1)

@@ -1,4 +1,5 @@
-"""Timings of the DQN kernels on one GPU (development tool): act (B=1), forward and learn at B=512."""
+"""Timings of the DQN kernels on one GPU (development tool): act (B=1), forward and learn at B=512, from float
+states and from the uint8 observations a device replay memory holds."""
 import argparse
 import json
 import os
@@ -58,6 +59,9 @@ def main():
     t = timed(lambda: agent.learn((s, act, r, sn, d), 0.99))
     out["learn_ms"] = t
     out["learn_TFLOPs_5x_forward"] = 5 * fwd_flop / t / 1e9
+    obs_n = torch.randint(0, 3, (B, 3, ps), generator=g, dtype=torch.uint8).cuda()
+    t = timed(lambda: agent.learn_obs((obs, act, r, obs_n, d), 0.99, ps))
+    out["learn_u8_ms"] = t
     print(json.dumps(out))
 
 
