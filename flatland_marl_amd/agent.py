@@ -107,7 +107,7 @@ class DQNAgent:
         local = self.qnetwork_local.flat_params()
         target = self.qnetwork_target.flat_params()
         dev = local.device
-        n_ws = query("flm_dqn_learn_workspace", B, self.height, self.width)
+        n_ws = query("flm_dqn_learn_workspace", B, self.height, self.width, self.action_space)
         if self._ws is None or self._ws.numel() < n_ws or self._ws.device != dev:
             self._ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
         s = states.to(dev, torch.float32).contiguous().view(B, self.height, self.width)
@@ -118,7 +118,8 @@ class DQNAgent:
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         self.optimizer.zero_grad()
         call("flm_dqn_learn_grads", ptr(local), ptr(target), ptr(s), ptr(sn), ptr(a), ptr(r), ptr(d), float(gamma),
-             1 if self.double_dqn else 0, B, self.height, self.width, ptr(self._ws), ptr(self.optimizer.grads), ptr(loss),
+             1 if self.double_dqn else 0, B, self.height, self.width, self.action_space, ptr(self._ws),
+             ptr(self.optimizer.grads), ptr(loss),
              torch.cuda.current_stream(dev).cuda_stream)
         parallel.allreduce_mean_(self.optimizer.grads)      # data parallel: one bucket, RCCL over xGMI
         self.last_loss = loss
@@ -135,7 +136,7 @@ class DQNAgent:
         local = self.qnetwork_local.flat_params()
         target = self.qnetwork_target.flat_params()
         dev = local.device
-        n_ws = query("flm_dqn_learn_workspace_u8", B, Rp, self.width)
+        n_ws = query("flm_dqn_learn_workspace_u8", B, Rp, self.width, self.action_space)
         if self._ws is None or self._ws.numel() < n_ws or self._ws.device != dev:
             self._ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
         s, sn = states.contiguous(), next_states.contiguous()
@@ -147,7 +148,8 @@ class DQNAgent:
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         self.optimizer.zero_grad()
         call("flm_dqn_learn_grads_u8", ptr(local), ptr(target), ptr(s), ptr(sn), int(plane_stride), ptr(a), ptr(r), ptr(d),
-             float(gamma), 1 if self.double_dqn else 0, B, Rp, self.width, ptr(self._ws), ptr(self.optimizer.grads), ptr(loss),
+             float(gamma), 1 if self.double_dqn else 0, B, Rp, self.width, self.action_space, ptr(self._ws),
+             ptr(self.optimizer.grads), ptr(loss),
              torch.cuda.current_stream(dev).cuda_stream)
         parallel.allreduce_mean_(self.optimizer.grads)      # data parallel: one bucket, RCCL over xGMI
         self.last_loss = loss

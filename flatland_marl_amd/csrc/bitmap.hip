@@ -790,4 +790,4 @@ extern "C" int flm_bitmaps_static(const int32_t* path_cell, const int32_t* path_
                      n_paths, H, W, capR, Rp, T1, plane_stride, Lcap, shift, ws, planes, err, stream);
 }
 
-extern "C" int flm_abi_version(void) { return 2; }
+extern "C" int flm_abi_version(void) { return 3; }

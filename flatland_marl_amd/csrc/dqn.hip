@@ -4,10 +4,11 @@
 // Network (src/model.py:11-43 of the reference), H3 = 3*max_rails rows, T1 = depth+1 columns:
 //   x[B,1,H3,T1] -> Conv2d(1,64,(1,T1)) + ReLU  == per row a dot product with 64 filters
 //                -> flatten as [c*H3 + h]       -> fc1_adv, fc1_val (64*H3 -> 512) + ReLU
-//                -> fc2_adv (512 -> 2), fc2_val (512 -> 1) -> q = val + adv - mean(adv)
+//                -> fc2_adv (512 -> NA), fc2_val (512 -> 1) -> q = val + adv - mean(adv)
+// NA = the reference's action_space (2 in src/main.py:92), at most FLM_DQN_MAX_ACTIONS.
 // Parameters live in one flat fp32 buffer in the order of the module's parameters():
 //   conv1.weight[64,T1] conv1.bias[64] fc1_adv.weight[512,K1] fc1_adv.bias[512] fc1_val.weight[512,K1]
-//   fc1_val.bias[512] fc2_adv.weight[2,512] fc2_adv.bias[2] fc2_val.weight[1,512] fc2_val.bias[1],  K1 = 64*H3.
+//   fc1_val.bias[512] fc2_adv.weight[NA,512] fc2_adv.bias[NA] fc2_val.weight[1,512] fc2_val.bias[1],  K1 = 64*H3.
 #include <type_traits>
 
 #include "flm_common.h"
@@ -17,10 +18,10 @@ namespace flm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct DqnLayout {
-  int H3, T1;
+  int H3, T1, NA;
   long K1;
   long conv_w, conv_b, a1_w, a1_b, v1_w, v1_b, a2_w, a2_b, v2_w, v2_b, total;
-  __host__ __device__ DqnLayout(int h3, int t1) : H3(h3), T1(t1) {
+  __host__ __device__ DqnLayout(int h3, int t1, int na) : H3(h3), T1(t1), NA(na) {
     K1 = 64L * h3;
     conv_w = 0;
     conv_b = conv_w + 64L * t1;
@@ -29,8 +30,8 @@ struct DqnLayout {
     v1_w = a1_b + 512;
     v1_b = v1_w + 512 * K1;
     a2_w = v1_b + 512;
-    a2_b = a2_w + 1024;
-    v2_w = a2_b + 2;
+    a2_b = a2_w + 512L * na;
+    v2_w = a2_b + na;
     v2_b = v2_w + 512;
     total = v2_b + 1;
   }
@@ -432,31 +433,43 @@ __global__ __launch_bounds__(1024) void fc1_rows_kernel(const float* __restrict_
 }
 
 // ---- output layers + dueling combination, one wave per sample ------------------------------------------
-// hid[B,1024]: columns 0..511 advantage stream, 512..1023 value stream.  q[B,2].
+// hid[B,1024]: columns 0..511 advantage stream, 512..1023 value stream.  q[B,NA], NA <= FLM_DQN_MAX_ACTIONS.
 __global__ __launch_bounds__(64) void head_forward_kernel(const float* __restrict__ hid, const float* __restrict__ a2w,
                                                           const float* __restrict__ a2b, const float* __restrict__ v2w,
-                                                          const float* __restrict__ v2b, int B, float* __restrict__ q) {
+                                                          const float* __restrict__ v2b, int B, int NA, float* __restrict__ q) {
   const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= B) return;
   const float* h = hid + (long)b * 1024;
-  float s0 = 0.f, s1 = 0.f, sv = 0.f;
+  float sa[FLM_DQN_MAX_ACTIONS], sv = 0.f;
+#pragma unroll
+  for (int a = 0; a < FLM_DQN_MAX_ACTIONS; a++) sa[a] = 0.f;
   for (int i = lane; i < 512; i += 64) {
     const float ha = h[i], hv = h[512 + i];
-    s0 = fmaf(ha, a2w[i], s0);
-    s1 = fmaf(ha, a2w[512 + i], s1);
+#pragma unroll
+    for (int a = 0; a < FLM_DQN_MAX_ACTIONS; a++)
+      if (a < NA) sa[a] = fmaf(ha, a2w[a * 512 + i], sa[a]);
     sv = fmaf(hv, v2w[i], sv);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    s0 += __shfl_down(s0, o);
-    s1 += __shfl_down(s1, o);
+#pragma unroll
+    for (int a = 0; a < FLM_DQN_MAX_ACTIONS; a++)
+      if (a < NA) sa[a] += __shfl_down(sa[a], o);
     sv += __shfl_down(sv, o);
   }
   if (lane == 0) {
-    const float adv0 = s0 + a2b[0], adv1 = s1 + a2b[1], val = sv + v2b[0];
-    const float mean = (adv0 + adv1) * 0.5f;
-    q[b * 2 + 0] = val + adv0 - mean;
-    q[b * 2 + 1] = val + adv1 - mean;
+    const float val = sv + v2b[0];
+    float sum = 0.f;
+#pragma unroll
+    for (int a = 0; a < FLM_DQN_MAX_ACTIONS; a++)
+      if (a < NA) {
+        sa[a] += a2b[a];
+        sum += sa[a];
+      }
+    const float mean = NA == 2 ? sum * 0.5f : sum / (float)NA;
+#pragma unroll
+    for (int a = 0; a < FLM_DQN_MAX_ACTIONS; a++)
+      if (a < NA) q[b * NA + a] = val + sa[a] - mean;
   }
 }
 
@@ -465,17 +478,18 @@ __global__ __launch_bounds__(64) void head_forward_kernel(const float* __restric
 //   loss = mean_b (q[b,action[b]] - target)^2;  dq[b,a] = 2*(q - target)/B on the taken action, else 0
 __global__ void td_loss_kernel(const float* __restrict__ q, const float* __restrict__ q_next_local,
                                const float* __restrict__ q_next_target, const int64_t* __restrict__ action,
-                               const float* __restrict__ reward, const float* __restrict__ done, float gamma, int B,
+                               const float* __restrict__ reward, const float* __restrict__ done, float gamma, int B, int NA,
                                float* __restrict__ dq, float* __restrict__ sq_err) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const int astar = q_next_local[b * 2 + 1] > q_next_local[b * 2 + 0] ? 1 : 0;
-  const float target = reward[b] + (gamma * q_next_target[b * 2 + astar]) * (1.f - done[b]);
-  const int a = (int)action[b];
-  const float diff = q[b * 2 + a] - target;
+  int astar = 0;                                   // the first maximum
+  for (int a = 1; a < NA; a++)
+    if (q_next_local[b * NA + a] > q_next_local[b * NA + astar]) astar = a;
+  const float target = reward[b] + (gamma * q_next_target[b * NA + astar]) * (1.f - done[b]);
+  const int a = (int)min(max(action[b], (int64_t)0), (int64_t)(NA - 1));   // a bad index must not leave the row
+  const float diff = q[b * NA + a] - target;
   sq_err[b] = diff * diff;
-  dq[b * 2 + a] = 2.f * diff / (float)B;
-  dq[b * 2 + (1 - a)] = 0.f;
+  for (int k = 0; k < NA; k++) dq[b * NA + k] = k == a ? 2.f * diff / (float)B : 0.f;
 }
 
 // The reference's target without double DQN (src/agent.py:103-105).  Its Q_targets_next keeps a trailing axis
@@ -488,13 +502,14 @@ __global__ void td_loss_kernel(const float* __restrict__ q, const float* __restr
 __global__ __launch_bounds__(1024) void td_loss_plain_kernel(const float* __restrict__ q, const float* __restrict__ q_next_target,
                                                              const int64_t* __restrict__ action,
                                                              const float* __restrict__ reward, const float* __restrict__ done,
-                                                             float gamma, int B, float* __restrict__ dq,
+                                                             float gamma, int B, int NA, float* __restrict__ dq,
                                                              float* __restrict__ sq_err) {
   __shared__ double s1[1024], s2[1024];
   const int tid = threadIdx.x;
   double a1 = 0.0, a2 = 0.0;
   for (int b = tid; b < B; b += 1024) {
-    const float m = fmaxf(q_next_target[b * 2], q_next_target[b * 2 + 1]);
+    float m = q_next_target[b * NA];
+    for (int k = 1; k < NA; k++) m = fmaxf(m, q_next_target[b * NA + k]);
     a1 += (double)m;
     a2 += (double)m * (double)m;
   }
@@ -510,12 +525,11 @@ __global__ __launch_bounds__(1024) void td_loss_plain_kernel(const float* __rest
   }
   const float m1 = (float)(s1[0] / (double)B), m2 = (float)(s2[0] / (double)B);
   for (int b = tid; b < B; b += 1024) {
-    const int a = (int)action[b];
-    const float u = q[b * 2 + a] - reward[b];
+    const int a = (int)min(max(action[b], (int64_t)0), (int64_t)(NA - 1));
+    const float u = q[b * NA + a] - reward[b];
     const float c = gamma * (1.f - done[b]);
     sq_err[b] = u * u - 2.f * u * c * m1 + c * c * m2;
-    dq[b * 2 + a] = 2.f * (u - c * m1) / (float)B;
-    dq[b * 2 + (1 - a)] = 0.f;
+    for (int k = 0; k < NA; k++) dq[b * NA + k] = k == a ? 2.f * (u - c * m1) / (float)B : 0.f;
   }
 }
 
@@ -527,82 +541,77 @@ __global__ __launch_bounds__(64) void mean_kernel(const float* __restrict__ x, i
   if (threadIdx.x == 0) *out = s / (float)n;
 }
 
-// Backward of the head: from dq[B,2] to the hidden-layer gradient dhid[B,1024] (ReLU applied) and the
+// Backward of the head: from dq[B,NA] to the hidden-layer gradient dhid[B,1024] (ReLU applied) and the
 // gradients of the four small tensors.  One wave per sample writes dhid; the small tensors are reduced
 // by a second kernel over the batch in a fixed order.
 __global__ __launch_bounds__(64) void head_backward_hidden_kernel(const float* __restrict__ hid, const float* __restrict__ dq,
                                                                   const float* __restrict__ a2w, const float* __restrict__ v2w,
-                                                                  int B, float* __restrict__ dhid, float* __restrict__ dadv,
-                                                                  float* __restrict__ dval) {
+                                                                  int B, int NA, float* __restrict__ dhid,
+                                                                  float* __restrict__ dadv, float* __restrict__ dval) {
   const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= B) return;
-  const float d0 = dq[b * 2], d1 = dq[b * 2 + 1];
-  const float dv = d0 + d1;
-  const float da0 = d0 - 0.5f * (d0 + d1), da1 = d1 - 0.5f * (d0 + d1);
+  // q = val + adv - mean(adv):  dval = sum_a dq[a],  dadv[a] = dq[a] - dval / NA
+  float da[FLM_DQN_MAX_ACTIONS], dv = 0.f;
+#pragma unroll
+  for (int a = 0; a < FLM_DQN_MAX_ACTIONS; a++) {
+    da[a] = a < NA ? dq[b * NA + a] : 0.f;
+    dv += da[a];
+  }
+  const float mean = NA == 2 ? 0.5f * dv : dv / (float)NA;
+#pragma unroll
+  for (int a = 0; a < FLM_DQN_MAX_ACTIONS; a++) da[a] -= mean;
   const float* h = hid + (long)b * 1024;
   float* dh = dhid + (long)b * 1024;
   for (int i = lane; i < 512; i += 64) {
-    const float ga = da0 * a2w[i] + da1 * a2w[512 + i];
+    float ga = 0.f;
+#pragma unroll
+    for (int a = 0; a < FLM_DQN_MAX_ACTIONS; a++)
+      if (a < NA) ga = a == 0 ? da[0] * a2w[i] : ga + da[a] * a2w[a * 512 + i];
     dh[i] = h[i] > 0.f ? ga : 0.f;
     const float gv = dv * v2w[i];
     dh[512 + i] = h[512 + i] > 0.f ? gv : 0.f;
   }
   if (lane == 0) {
-    dadv[b * 2] = da0;
-    dadv[b * 2 + 1] = da1;
+#pragma unroll
+    for (int a = 0; a < FLM_DQN_MAX_ACTIONS; a++)
+      if (a < NA) dadv[b * NA + a] = da[a];
     dval[b] = dv;
   }
 }
 
 // g_a2w[a,i] = sum_b dadv[b,a]*hid[b,i]; g_a2b[a] = sum_b dadv[b,a]; g_v2w[i] = sum_b dval[b]*hid[b,512+i]; g_v2b
 __global__ __launch_bounds__(1024) void head_backward_params_kernel(const float* __restrict__ hid, const float* __restrict__ dadv,
-                                                                    const float* __restrict__ dval, int B,
+                                                                    const float* __restrict__ dval, int B, int NA,
                                                                     float* __restrict__ g_a2w, float* __restrict__ g_a2b,
                                                                     float* __restrict__ g_v2w, float* __restrict__ g_v2b) {
-  // workgroup = 64 hidden units; 16 waves take every 16th sample each, their sums meet in LDS in wave order
-  __shared__ float s[3][16][64];
+  // workgroup = (64 hidden units, one output: blockIdx.y < NA an action's advantage row, blockIdx.y == NA the value
+  // row); 16 waves take every 16th sample each, their sums meet in LDS in wave order
+  __shared__ float s[16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + lane;
-  float s0 = 0.f, s1 = 0.f, sv = 0.f;
+  const int i = blockIdx.x * 64 + lane, a = blockIdx.y;
+  const bool value = a == NA;
+  float acc = 0.f;
   for (int b = w; b < B; b += 16) {
-    const float ha = hid[(long)b * 1024 + i], hv = hid[(long)b * 1024 + 512 + i];
-    s0 = fmaf(dadv[b * 2], ha, s0);
-    s1 = fmaf(dadv[b * 2 + 1], ha, s1);
-    sv = fmaf(dval[b], hv, sv);
+    const float d = value ? dval[b] : dadv[b * NA + a];
+    acc = fmaf(d, hid[(long)b * 1024 + (value ? 512 : 0) + i], acc);
   }
-  s[0][w][lane] = s0;
-  s[1][w][lane] = s1;
-  s[2][w][lane] = sv;
+  s[w][lane] = acc;
   __syncthreads();
   if (w == 0) {
-    float t0 = 0.f, t1 = 0.f, tv = 0.f;
+    float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      t0 += s[0][k][lane];
-      t1 += s[1][k][lane];
-      tv += s[2][k][lane];
-    }
-    g_a2w[i] = t0;
-    g_a2w[512 + i] = t1;
-    g_v2w[i] = tv;
+    for (int k = 0; k < 16; k++) t += s[k][lane];
+    if (value) g_v2w[i] = t;
+    else g_a2w[a * 512 + i] = t;
   }
-  if (blockIdx.x == 0 && w == 1) {   // the three bias gradients: one wave, lanes stride over the batch
-    float b0 = 0.f, b1 = 0.f, bv = 0.f;
-    for (int b = lane; b < B; b += 64) {
-      b0 += dadv[b * 2];
-      b1 += dadv[b * 2 + 1];
-      bv += dval[b];
-    }
+  if (blockIdx.x == 0 && w == 1) {   // this output's bias gradient: one wave, lanes stride over the batch
+    float bsum = 0.f;
+    for (int b = lane; b < B; b += 64) bsum += value ? dval[b] : dadv[b * NA + a];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      b0 += __shfl_xor(b0, o);
-      b1 += __shfl_xor(b1, o);
-      bv += __shfl_xor(bv, o);
-    }
+    for (int o = 32; o > 0; o >>= 1) bsum += __shfl_xor(bsum, o);
     if (lane == 0) {
-      g_a2b[0] = b0;
-      g_a2b[1] = b1;
-      g_v2b[0] = bv;
+      if (value) g_v2b[0] = bsum;
+      else g_a2b[a] = bsum;
     }
   }
 }
@@ -895,7 +904,9 @@ static int fc1_k_slices(int B) {
 using flm::DqnLayout;
 using flm::GemmArgs;
 
-extern "C" long flm_dqn_param_count(int H3, int T1) { return DqnLayout(H3, T1).total; }
+static bool actions_ok(int NA) { return NA >= 1 && NA <= FLM_DQN_MAX_ACTIONS; }
+
+extern "C" long flm_dqn_param_count(int H3, int T1, int NA) { return actions_ok(NA) ? DqnLayout(H3, T1, NA).total : 0; }
 
 // workspace floats needed by flm_dqn_forward for a batch of B samples
 extern "C" long flm_dqn_forward_workspace(int B, int H3) {
@@ -904,8 +915,8 @@ extern "C" long flm_dqn_forward_workspace(int B, int H3) {
 
 // x: float input [B,H3,T1], or nullptr when the input is obs_u8 [B,3,plane_stride] (H3 = 3*Rp)
 static int dqn_forward_impl(const float* params, const float* x, const uint8_t* obs_u8, int plane_stride, int B, int H3,
-                            int T1, float* x1, float* hid, float* part, float* q, hipStream_t stream) {
-  DqnLayout L(H3, T1);
+                            int T1, int NA, float* x1, float* hid, float* part, float* q, hipStream_t stream) {
+  DqnLayout L(H3, T1, NA);
   GemmArgs g{};
   int rc;
   // small batches (act): the first dense layer streams both weight matrices in one launch
@@ -974,29 +985,30 @@ static int dqn_forward_impl(const float* params, const float* x, const uint8_t* 
                        1024, params + L.a1_b, params + L.v1_b, 512, hid, 1024L);
   }
   hipLaunchKernelGGL(flm::head_forward_kernel, dim3(B), dim3(64), 0, stream, hid, params + L.a2_w, params + L.a2_b,
-                     params + L.v2_w, params + L.v2_b, B, q);
+                     params + L.v2_w, params + L.v2_b, B, NA, q);
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
 }
 
-extern "C" int flm_dqn_forward(const float* params, const float* x, int B, int H3, int T1, float* workspace, float* q,
-                               void* stream) {
-  if (!params || !x || !workspace || !q || B <= 0 || H3 <= 0 || T1 <= 0) return FLM_E_ARG;
+extern "C" int flm_dqn_forward(const float* params, const float* x, int B, int H3, int T1, int NA, float* workspace,
+                               float* q, void* stream) {
+  if (!params || !x || !workspace || !q || B <= 0 || H3 <= 0 || T1 <= 0 || !actions_ok(NA)) return FLM_E_ARG;
   float* x1 = workspace;
   float* hid = workspace + (long)B * 64 * H3;
   float* part = hid + (long)B * 1024;
-  return dqn_forward_impl(params, x, nullptr, 0, B, H3, T1, x1, hid, part, q, (hipStream_t)stream);
+  return dqn_forward_impl(params, x, nullptr, 0, B, H3, T1, NA, x1, hid, part, q, (hipStream_t)stream);
 }
 
-extern "C" int flm_dqn_forward_u8(const float* params, const uint8_t* obs, int n, int Rp, int T1, int plane_stride,
+extern "C" int flm_dqn_forward_u8(const float* params, const uint8_t* obs, int n, int Rp, int T1, int plane_stride, int NA,
                                   float* workspace, float* q, void* stream) {
-  if (!params || !obs || !workspace || !q || n <= 0 || Rp <= 0 || T1 <= 0 || (long)plane_stride < (long)Rp * T1)
+  if (!params || !obs || !workspace || !q || n <= 0 || Rp <= 0 || T1 <= 0 || (long)plane_stride < (long)Rp * T1 ||
+      !actions_ok(NA))
     return FLM_E_ARG;
   const int H3 = 3 * Rp;
   float* x1 = workspace;
   float* hid = workspace + (long)n * 64 * H3;
   float* part = hid + (long)n * 1024;
-  return dqn_forward_impl(params, nullptr, obs, plane_stride, n, H3, T1, x1, hid, part, q, (hipStream_t)stream);
+  return dqn_forward_impl(params, nullptr, obs, plane_stride, n, H3, T1, NA, x1, hid, part, q, (hipStream_t)stream);
 }
 
 extern "C" int flm_obs_to_f32(const uint8_t* obs, int n, int Rp, int T1, int plane_stride, float* out, void* stream) {
@@ -1008,14 +1020,15 @@ extern "C" int flm_obs_to_f32(const uint8_t* obs, int n, int Rp, int T1, int pla
 }
 
 // workspace floats needed by flm_dqn_learn_grads
-extern "C" long flm_dqn_learn_workspace(int B, int H3, int T1) {
+extern "C" long flm_dqn_learn_workspace(int B, int H3, int T1, int NA) {
+  if (!actions_ok(NA)) return 0;
   const long act = (long)B * 64 * H3 + (long)B * 1024;        // x1 + hid of one forward
   return 3 * act                                              // three forwards
          + (long)B * 1024                                     // dhid
          + (long)B * 64 * H3                                  // dx1
          + (long)B * 64 * T1                                  // per-sample conv weight partials
          + (long)fc1_k_slices(B) * B * 1024                   // split-K partials of the first dense layer
-         + 16L * B + 64;                                      // q's, dq, dadv, dval, squared errors, loss
+         + (((5L * NA + 2) * B + 64 + 3) & ~3L);              // three q's, dq, dadv; dval, squared errors (whole 16 bytes)
 }
 
 // Forward passes, loss and backward of one learn step (src/agent.py:94-114); grads gets dLoss/dparams of
@@ -1026,8 +1039,8 @@ extern "C" long flm_dqn_learn_workspace(int B, int H3, int T1) {
 static int learn_grads_impl(const float* local, const float* target, const float* s, const float* s_next,
                             const uint8_t* s_u8, const uint8_t* sn_u8, int plane_stride, const int64_t* action,
                             const float* reward, const float* done, float gamma, int double_dqn, int B, int H3, int T1,
-                            float* ws, float* grads, float* loss_out, hipStream_t stream) {
-  DqnLayout L(H3, T1);
+                            int NA, float* ws, float* grads, float* loss_out, hipStream_t stream) {
+  DqnLayout L(H3, T1, NA);
   const long n_x1 = (long)B * 64 * H3, n_hid = (long)B * 1024;
   float* x1 = ws;            float* hid = x1 + n_x1;
   float* x1n = hid + n_hid;  float* hidn = x1n + n_x1;
@@ -1037,33 +1050,33 @@ static int learn_grads_impl(const float* local, const float* target, const float
   float* cpart = dx1 + n_x1;
   float* part = cpart + (long)B * 64 * T1;
   float* q = part + (long)fc1_k_slices(B) * B * 1024;
-  float* qn = q + 2 * B; float* qt = qn + 2 * B; float* dq = qt + 2 * B;
-  float* dadv = dq + 2 * B; float* dval = dadv + 2 * B; float* sq = dval + B;
+  float* qn = q + (long)NA * B; float* qt = qn + (long)NA * B; float* dq = qt + (long)NA * B;
+  float* dadv = dq + (long)NA * B; float* dval = dadv + (long)NA * B; float* sq = dval + B;
   int rc;
   if (s_u8) {
     hipLaunchKernelGGL(flm::obs_to_f32_kernel, dim3(2048), dim3(256), 0, stream, s_u8, B, H3 / 3, T1, plane_stride,
                        const_cast<float*>(s));
     if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   }
-  if ((rc = dqn_forward_impl(local, s_u8 ? nullptr : s, s_u8, plane_stride, B, H3, T1, x1, hid, part, q, stream))) return rc;
+  if ((rc = dqn_forward_impl(local, s_u8 ? nullptr : s, s_u8, plane_stride, B, H3, T1, NA, x1, hid, part, q, stream))) return rc;
   // the local network's view of the next states picks the action only under double DQN
   if (double_dqn &&
-      (rc = dqn_forward_impl(local, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, x1n, hidn, part, qn, stream)))
+      (rc = dqn_forward_impl(local, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, NA, x1n, hidn, part, qn, stream)))
     return rc;
-  if ((rc = dqn_forward_impl(target, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, x1t, hidt, part, qt, stream)))
+  if ((rc = dqn_forward_impl(target, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, NA, x1t, hidt, part, qt, stream)))
     return rc;
   if (double_dqn)
     hipLaunchKernelGGL(flm::td_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, q, qn, qt, action, reward, done,
-                       gamma, B, dq, sq);
+                       gamma, B, NA, dq, sq);
   else
-    hipLaunchKernelGGL(flm::td_loss_plain_kernel, dim3(1), dim3(1024), 0, stream, q, qt, action, reward, done, gamma, B, dq,
-                       sq);
+    hipLaunchKernelGGL(flm::td_loss_plain_kernel, dim3(1), dim3(1024), 0, stream, q, qt, action, reward, done, gamma, B, NA,
+                       dq, sq);
   hipLaunchKernelGGL(flm::mean_kernel, dim3(1), dim3(64), 0, stream, sq, B, loss_out);
   // head
   hipLaunchKernelGGL(flm::head_backward_hidden_kernel, dim3(B), dim3(64), 0, stream, hid, dq, local + L.a2_w, local + L.v2_w, B,
-                     dhid, dadv, dval);
-  hipLaunchKernelGGL(flm::head_backward_params_kernel, dim3(8), dim3(1024), 0, stream, hid, dadv, dval, B, grads + L.a2_w,
-                     grads + L.a2_b, grads + L.v2_w, grads + L.v2_b);
+                     NA, dhid, dadv, dval);
+  hipLaunchKernelGGL(flm::head_backward_params_kernel, dim3(8, NA + 1), dim3(1024), 0, stream, hid, dadv, dval, B, NA,
+                     grads + L.a2_w, grads + L.a2_b, grads + L.v2_w, grads + L.v2_b);
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   // first dense layer: weight gradients dW[n,j] = sum_b dhid[b,n] * x1[b,j], both streams as two groups of one launch
   // (more workgroups per launch: fewer idle matrix pipes in the last round); bias gradients = column sums
@@ -1106,28 +1119,29 @@ static int learn_grads_impl(const float* local, const float* target, const float
 
 extern "C" int flm_dqn_learn_grads(const float* local, const float* target, const float* s, const float* s_next,
                                    const int64_t* action, const float* reward, const float* done, float gamma,
-                                   int double_dqn, int B, int H3, int T1, float* ws, float* grads, float* loss_out,
-                                   void* stream) {
+                                   int double_dqn, int B, int H3, int T1, int NA, float* ws, float* grads,
+                                   float* loss_out, void* stream) {
   if (!local || !target || !s || !s_next || !action || !reward || !done || !ws || !grads || !loss_out) return FLM_E_ARG;
-  if (B <= 0 || H3 <= 0 || T1 <= 0) return FLM_E_ARG;
+  if (B <= 0 || H3 <= 0 || T1 <= 0 || !actions_ok(NA)) return FLM_E_ARG;
   return learn_grads_impl(local, target, s, s_next, nullptr, nullptr, 0, action, reward, done, gamma, double_dqn, B, H3, T1,
-                          ws, grads, loss_out, (hipStream_t)stream);
+                          NA, ws, grads, loss_out, (hipStream_t)stream);
 }
 
-extern "C" long flm_dqn_learn_workspace_u8(int B, int Rp, int T1) {
-  return flm_dqn_learn_workspace(B, 3 * Rp, T1) + (long)B * 3 * Rp * T1;
+extern "C" long flm_dqn_learn_workspace_u8(int B, int Rp, int T1, int NA) {
+  if (!actions_ok(NA)) return 0;
+  return flm_dqn_learn_workspace(B, 3 * Rp, T1, NA) + (long)B * 3 * Rp * T1;
 }
 
 extern "C" int flm_dqn_learn_grads_u8(const float* local, const float* target, const uint8_t* s, const uint8_t* s_next,
                                       int plane_stride, const int64_t* action, const float* reward, const float* done,
-                                      float gamma, int double_dqn, int B, int Rp, int T1, float* ws, float* grads,
-                                      float* loss_out, void* stream) {
+                                      float gamma, int double_dqn, int B, int Rp, int T1, int NA, float* ws,
+                                      float* grads, float* loss_out, void* stream) {
   if (!local || !target || !s || !s_next || !action || !reward || !done || !ws || !grads || !loss_out) return FLM_E_ARG;
-  if (B <= 0 || Rp <= 0 || T1 <= 0 || (long)plane_stride < (long)Rp * T1) return FLM_E_ARG;
+  if (B <= 0 || Rp <= 0 || T1 <= 0 || (long)plane_stride < (long)Rp * T1 || !actions_ok(NA)) return FLM_E_ARG;
   const int H3 = 3 * Rp;
-  float* s_f32 = ws + flm_dqn_learn_workspace(B, H3, T1);     // the float copy of s lives behind the common workspace
+  float* s_f32 = ws + flm_dqn_learn_workspace(B, H3, T1, NA);   // the float copy of s lives behind the common workspace
   return learn_grads_impl(local, target, s_f32, nullptr, s, s_next, plane_stride, action, reward, done, gamma, double_dqn, B,
-                          H3, T1, ws, grads, loss_out, (hipStream_t)stream);
+                          H3, T1, NA, ws, grads, loss_out, (hipStream_t)stream);
 }
 
 extern "C" int flm_dqn_adam(float* params, const float* grads, float* m, float* v, long n, double lr, double beta1,

@@ -10,8 +10,9 @@ from ._lib import call, ptr, query
 class Dueling_DQN(nn.Module):
     def __init__(self, width, height, action_space):
         super(Dueling_DQN, self).__init__()
-        if action_space != 2:
-            raise ValueError("the device kernels implement the reference's two actions (stop/go)")
+        action_space = int(action_space)
+        if not 1 <= action_space <= _lib.DQN_MAX_ACTIONS:
+            raise ValueError("action_space must be 1..%d for the device kernels" % _lib.DQN_MAX_ACTIONS)
         self.action_space = action_space
         self.width, self.height = int(width), int(height)
         # same submodules in the same order as the reference => identical default init and state_dict keys
@@ -42,7 +43,7 @@ class Dueling_DQN(nn.Module):
                 off += p.numel()
         if not ok:
             n = sum(p.numel() for p in params)
-            assert n == query("flm_dqn_param_count", self.height, self.width)
+            assert n == query("flm_dqn_param_count", self.height, self.width, self.action_space)
             flat = torch.empty(n, dtype=torch.float32, device=dev)
             off = 0
             for p in params:
@@ -80,21 +81,22 @@ class Dueling_DQN(nn.Module):
         x = x.to(device=flat.device, dtype=torch.float32).contiguous()
         B = x.size(0)
         x = x.view(B, self.height, self.width)
-        q = torch.empty((B, 2), dtype=torch.float32, device=flat.device)
-        call("flm_dqn_forward", ptr(flat), ptr(x), B, self.height, self.width, ptr(self._workspace(B)), ptr(q),
+        q = torch.empty((B, self.action_space), dtype=torch.float32, device=flat.device)
+        call("flm_dqn_forward", ptr(flat), ptr(x), B, self.height, self.width, self.action_space,
+             ptr(self._workspace(B)), ptr(q),
              torch.cuda.current_stream(flat.device).cuda_stream)
         return q
 
     def forward_obs(self, obs_u8, plane_stride):
-        """Q-values [n,2] straight from uint8 observations [n,3,plane_stride] (plane 0 int8, heat planes uint8,
+        """Q-values [n,action_space] straight from uint8 observations [n,3,plane_stride] (plane 0 int8, heat planes uint8,
         rows of `width` bytes): the convolution reads the bytes, no float copy of the input is made."""
         flat = self.flat_params()
         if self.height % 3:
             raise ValueError("observations have three planes: the network height must be 3*max_rails")
         obs_u8 = obs_u8.contiguous()
         n = obs_u8.size(0)
-        q = torch.empty((n, 2), dtype=torch.float32, device=flat.device)
+        q = torch.empty((n, self.action_space), dtype=torch.float32, device=flat.device)
         call("flm_dqn_forward_u8", ptr(flat), ptr(obs_u8), n, self.height // 3, self.width, int(plane_stride),
-             ptr(self._workspace(n)), ptr(q), torch.cuda.current_stream(flat.device).cuda_stream)
+             self.action_space, ptr(self._workspace(n)), ptr(q), torch.cuda.current_stream(flat.device).cuda_stream)
         return q
 

@@ -44,6 +44,8 @@ class DQNPolicy:
     (agents e*A+a, their observations as shown to the network, the actions chosen)."""
 
     def __init__(self, agent, eps=0.0, seed=0, chunk_bytes=2 << 30):
+        if agent.action_space != 2:                        # the rollout's decision is stop (0) or go (1), src/main.py:163-213
+            raise ValueError("the rollout's policy chooses between two actions; the agent has %d" % agent.action_space)
         self.agent = agent
         self.eps = float(eps)
         self.chunk_bytes = int(chunk_bytes)

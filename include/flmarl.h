@@ -370,23 +370,25 @@ int flm_env_step(const uint16_t* grid, const int32_t* action, const int32_t* ini
 
 /* ---- Dueling Double-DQN (fp32; matrix products on the fp32 MFMA) -------------------------------------
  * Replaces Dueling_DQN.forward, src/model.py:31-43, and the numeric part of DQNAgent.act / learn /
- * soft_update, src/agent.py:69-131.  H3 = 3*max_rails input rows, T1 = depth+1 columns, 2 actions.
+ * soft_update, src/agent.py:69-131.  H3 = 3*max_rails input rows, T1 = depth+1 columns, NA = number of
+ * actions (the reference's action_space; src/main.py:92 uses 2), 1 <= NA <= FLM_DQN_MAX_ACTIONS.
  * Parameters are one flat float buffer in the order of the module's parameters():
  *   conv1.weight[64,T1] conv1.bias[64] fc1_adv.weight[512,64*H3] fc1_adv.bias[512] fc1_val.weight[512,64*H3]
- *   fc1_val.bias[512] fc2_adv.weight[2,512] fc2_adv.bias[2] fc2_val.weight[1,512] fc2_val.bias[1]. */
-long flm_dqn_param_count(int H3, int T1);
+ *   fc1_val.bias[512] fc2_adv.weight[NA,512] fc2_adv.bias[NA] fc2_val.weight[1,512] fc2_val.bias[1]. */
+#define FLM_DQN_MAX_ACTIONS 16
+long flm_dqn_param_count(int H3, int T1, int NA);
 long flm_dqn_forward_workspace(int B, int H3);              /* floats */
-long flm_dqn_learn_workspace(int B, int H3, int T1);        /* floats */
+long flm_dqn_learn_workspace(int B, int H3, int T1, int NA); /* floats */
 
-/* q[B,2] = network(x[B,H3,T1]).  workspace: flm_dqn_forward_workspace(B,H3) floats. */
-int flm_dqn_forward(const float* params, const float* x, int B, int H3, int T1, float* workspace, float* q,
+/* q[B,NA] = network(x[B,H3,T1]).  workspace: flm_dqn_forward_workspace(B,H3) floats. */
+int flm_dqn_forward(const float* params, const float* x, int B, int H3, int T1, int NA, float* workspace, float* q,
                     void* stream);
 
 /* The same forward pass straight from uint8 observations [n,3,plane_stride] (plane 0 int8, heat planes
  * uint8, rows of T1 bytes: what flm_observations* write): the convolution reads the bytes, no float copy
  * of the input is made.  workspace: flm_dqn_forward_workspace(n, 3*Rp) floats.
  * Limits (FLM_E_ARG beyond them): n*3*Rp < 2^31 rows; T1 <= 313 (a row tile and the filter bank share the LDS). */
-int flm_dqn_forward_u8(const float* params, const uint8_t* obs, int n, int Rp, int T1, int plane_stride,
+int flm_dqn_forward_u8(const float* params, const uint8_t* obs, int n, int Rp, int T1, int plane_stride, int NA,
                        float* workspace, float* q, void* stream);
 
 /* uint8 observations [n,3,plane_stride] (own plane int8) -> float rows [n,3*Rp,T1], the network's input. */
@@ -397,21 +399,22 @@ int flm_obs_to_f32(const uint8_t* obs, int n, int Rp, int T1, int plane_stride, 
  * the next state is the local network's, its value the target network's (:98-101); double_dqn == 0: the
  * reference's plain-DQN branch (:103-105) as it really computes - its next-state maxima keep a trailing axis, so
  * every sample is compared with the targets built from every sample's maximum ([B,B] broadcast inside mse_loss).
- * action int64 [B], reward/done float [B].  workspace: flm_dqn_learn_workspace floats.
+ * action int64 [B] in 0..NA-1 (values outside are clamped into the range), reward/done float [B].  workspace: flm_dqn_learn_workspace floats.
+ * The greedy action of a tie is the first maximum, as torch.max returns it.
  * The reference also back-propagates into the target network (its Q_targets are not detached); those
  * gradients are never used by the optimizer and are not computed here. */
 int flm_dqn_learn_grads(const float* local, const float* target, const float* s, const float* s_next,
                         const int64_t* action, const float* reward, const float* done, float gamma, int double_dqn,
-                        int B, int H3, int T1, float* workspace, float* grads, float* loss_out, void* stream);
+                        int B, int H3, int T1, int NA, float* workspace, float* grads, float* loss_out, void* stream);
 
 /* The same learn step on uint8 observations [B,3,plane_stride] as stored by a device replay memory: the
  * forward passes read the bytes; only the states s are expanded to float (inside the workspace) for the
- * convolution's weight gradient.  workspace: flm_dqn_learn_workspace_u8(B,Rp,T1) floats. */
-long flm_dqn_learn_workspace_u8(int B, int Rp, int T1);
+ * convolution's weight gradient.  workspace: flm_dqn_learn_workspace_u8(B,Rp,T1,NA) floats. */
+long flm_dqn_learn_workspace_u8(int B, int Rp, int T1, int NA);
 int flm_dqn_learn_grads_u8(const float* local, const float* target, const uint8_t* s, const uint8_t* s_next,
                            int plane_stride, const int64_t* action, const float* reward, const float* done, float gamma,
-                           int double_dqn, int B, int Rp, int T1, float* workspace, float* grads, float* loss_out,
-                           void* stream);
+                           int double_dqn, int B, int Rp, int T1, int NA, float* workspace, float* grads,
+                           float* loss_out, void* stream);
 
 /* Uniform sampling without replacement from a replay memory that lives in device memory, and the gather of the
  * sampled transitions.  Replaces ReplayBuffer.sample, src/agent.py:159-174 (random.sample over the deque, then

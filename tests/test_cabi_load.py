@@ -66,4 +66,5 @@ def test_entry_points_reject_null_and_zero_arguments():
         checked += 1
     assert checked >= 25
     # size queries answer 0 or a positive count, never garbage, for degenerate sizes
-    assert lib.flm_dqn_param_count(300, 151) == 19673091
+    assert lib.flm_dqn_param_count(300, 151, 2) == 19673091
+    assert lib.flm_dqn_param_count(300, 151, 5) == 19673091 + 3 * 513

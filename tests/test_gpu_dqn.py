@@ -33,6 +33,11 @@ def close_q(got, want, rtol=RTOL):
     return bool(np.all(np.abs(got - want) <= rtol * np.maximum(np.abs(want), floor)))
 
 
+def _no_warning():
+    import contextlib
+    return contextlib.nullcontext()
+
+
 def tensor_sums(flat, shapes):
     out, off = [], 0
     for shp in shapes:
@@ -163,6 +168,67 @@ def test_gradients_elementwise_vs_torch(B, H3, T1):
         agent.optimizer.v.copy_(torch.cat([st[i]["exp_avg_sq"].reshape(-1) for i in range(len(st))]))
 
 
+@pytest.mark.parametrize("NA,B,H3,T1,double_dqn", [(1, 20, 12, 21, True), (3, 40, 30, 21, True), (5, 130, 9, 151, True),
+                                                   (16, 33, 21, 37, True), (4, 24, 15, 31, False)])
+def test_other_action_spaces_elementwise_vs_torch(NA, B, H3, T1, double_dqn):
+    """action_space other than the training script's 2 (the constructor argument of src/model.py:11 and
+    src/agent.py:17): state_dict shapes, Q-values, loss and every gradient element against plain PyTorch fp32, for the
+    double-DQN target and the reference's plain branch with its [B,B] broadcast.  The reference's own goldens hold two actions only: these sizes are checked against PyTorch alone."""
+    import torch.nn.functional as F
+    from flatland_marl_amd.agent import DQNAgent
+    from tests.torch_ref_dqn import TorchDuelingDQN
+    torch.manual_seed(100 + NA)
+    args = argparse.Namespace(prediction_depth=T1 - 1, lr=0.001, buffer_size=10, batch_size=B, update_every=1,
+                              gamma=0.9, tau=0.05)
+    agent = DQNAgent(args, action_space=NA, bitmap_height=H3, double_dqn=double_dqn)
+    sd = agent.qnetwork_local.state_dict()
+    assert tuple(sd["fc2_adv.weight"].shape) == (NA, 512) and tuple(sd["fc2_adv.bias"].shape) == (NA,)
+    ref_local = TorchDuelingDQN(T1, H3, NA)
+    ref_local.load_state_dict(sd)
+    ref_target = copy.deepcopy(ref_local)
+    with torch.no_grad():
+        for p in ref_target.parameters():
+            p.mul_(0.9)
+    agent.qnetwork_target.load_state_dict(ref_target.state_dict())
+    g = torch.Generator().manual_seed(B + NA)
+    s = torch.randint(-1, 4, (B, 1, H3, T1), generator=g).float()
+    sn = torch.randint(-1, 4, (B, 1, H3, T1), generator=g).float()
+    a = torch.randint(0, NA, (B,), generator=g)
+    r = torch.randn(B, generator=g)
+    d = (torch.rand(B, generator=g) < 0.3).float()
+    for n in (1, 5, B):                          # the act path's kernels and the batched ones
+        got = agent.qnetwork_local(s[:n]).cpu().numpy()
+        assert got.shape == (n, NA)
+        assert close(got, ref_local(s[:n]).detach().numpy())
+    q = ref_local(s).gather(1, a.unsqueeze(-1)).view(B)
+    if double_dqn:
+        best = ref_local(sn).max(1)[1]
+        q_next = ref_target(sn).gather(1, best.unsqueeze(-1)).view(B)
+    else:
+        q_next = ref_target(sn).detach().max(1)[0].unsqueeze(-1)
+    with pytest.warns(UserWarning) if not double_dqn else _no_warning():
+        loss = F.mse_loss(q, r + args.gamma * q_next * (1 - d))
+    ref_local.zero_grad()
+    loss.backward()
+    agent.learn((s, a, r, sn, d), args.gamma)
+    assert close(agent.last_loss.cpu().numpy(), loss.detach().numpy())
+    off = 0
+    flat_g = agent.optimizer.grads.cpu().numpy()
+    for name, p in ref_local.named_parameters():
+        n = p.numel()
+        assert close(flat_g[off:off + n], p.grad.reshape(-1).numpy(), rtol=2e-5), name
+        off += n
+    assert off == flat_g.size
+
+
+def test_action_space_limits():
+    from flatland_marl_amd._lib import DQN_MAX_ACTIONS
+    from flatland_marl_amd.model import Dueling_DQN
+    for bad in (0, DQN_MAX_ACTIONS + 1):
+        with pytest.raises(ValueError):
+            Dueling_DQN(21, 12, bad)
+
+
 @pytest.mark.parametrize("H3,T1", [(21, 37), (300, 151), (12, 301)])
 def test_small_batch_forward_vs_torch(H3, T1):
     """The act path (batches of 1..8: the four-rows-per-workgroup convolution and the weight-streaming first dense
@@ -242,11 +308,11 @@ def test_learn_from_uint8_observations_matches_float_learn(Rp, T1, B, ps):
     target.mul_(1.01)                                           # make the two networks differ
     grads = torch.zeros((2, local.numel()), device="cuda")
     loss = torch.zeros((2, 1), device="cuda")
-    ws = torch.empty(query("flm_dqn_learn_workspace_u8", B, Rp, T1), device="cuda")
+    ws = torch.empty(query("flm_dqn_learn_workspace_u8", B, Rp, T1, 2), device="cuda")
     call("flm_dqn_learn_grads", ptr(local), ptr(target), ptr(f[0]), ptr(f[1]), ptr(act), ptr(rew), ptr(done), 0.99, 1, B,
-         3 * Rp, T1, ptr(ws), ptr(grads[0]), ptr(loss[0]), st)
+         3 * Rp, T1, 2, ptr(ws), ptr(grads[0]), ptr(loss[0]), st)
     call("flm_dqn_learn_grads_u8", ptr(local), ptr(target), ptr(obs[0]), ptr(obs[1]), ps, ptr(act), ptr(rew), ptr(done),
-         0.99, 1, B, Rp, T1, ptr(ws), ptr(grads[1]), ptr(loss[1]), st)
+         0.99, 1, B, Rp, T1, 2, ptr(ws), ptr(grads[1]), ptr(loss[1]), st)
     torch.cuda.synchronize()
     assert torch.allclose(loss[0], loss[1], rtol=1e-5)
     scale = grads[0].abs().max().item()
@@ -294,7 +360,7 @@ def test_learn_shape_of_the_benchmark_elementwise_vs_torch():
     assert close_q(agent.qnetwork_local.forward_obs(obs[0].cuda(), ps).cpu().numpy(), q_ref)
     local, target = agent.qnetwork_local.flat_params(), agent.qnetwork_target.flat_params()
     st = torch.cuda.current_stream().cuda_stream
-    ws = torch.empty(query("flm_dqn_learn_workspace_u8", B, Rp, T1), device="cuda")
+    ws = torch.empty(query("flm_dqn_learn_workspace_u8", B, Rp, T1, 2), device="cuda")
     dev = lambda t: t.cuda().contiguous()
     da, dr, dd, dx, dobs = dev(a), dev(r), dev(d), dev(x.view(2, B, H3, T1)), dev(obs)
     for which in ("float", "bytes"):
@@ -302,10 +368,10 @@ def test_learn_shape_of_the_benchmark_elementwise_vs_torch():
         loss = torch.zeros(1, device="cuda")
         if which == "float":
             call("flm_dqn_learn_grads", ptr(local), ptr(target), ptr(dx[0]), ptr(dx[1]), ptr(da), ptr(dr), ptr(dd), args.gamma,
-                 1, B, H3, T1, ptr(ws), ptr(grads), ptr(loss), st)
+                 1, B, H3, T1, 2, ptr(ws), ptr(grads), ptr(loss), st)
         else:
             call("flm_dqn_learn_grads_u8", ptr(local), ptr(target), ptr(dobs[0]), ptr(dobs[1]), ps, ptr(da), ptr(dr), ptr(dd),
-                 args.gamma, 1, B, Rp, T1, ptr(ws), ptr(grads), ptr(loss), st)
+                 args.gamma, 1, B, Rp, T1, 2, ptr(ws), ptr(grads), ptr(loss), st)
         torch.cuda.synchronize()
         assert close(loss.cpu().numpy(), loss_ref), which
         flat, off = grads.cpu().numpy(), 0
