@@ -1,5 +1,7 @@
-// Dueling Double-DQN of flatland-marl on gfx950: fp32 throughout, matrix products on the fp32 MFMA
-// (v_mfma_f32_32x32x2_f32: exact fp32 fused multiply-adds, no reduced-precision inputs).
+// Dueling Double-DQN of flatland-marl on gfx950: fp32 values and fp32 accumulation throughout.  The large matrix
+// products run on the bf16 matrix cores with every fp32 operand split into three bf16 terms (gemm_x3_kernel: the
+// result has the accuracy of an fp32 multiply-add); the convolution from bytes and the small-batch kernels use
+// fp32 instructions (v_mfma_f32_32x32x2_f32, v_fma_f32).
 //
 // Network (src/model.py:11-43 of the reference), H3 = 3*max_rails rows, T1 = depth+1 columns:
 //   x[B,1,H3,T1] -> Conv2d(1,64,(1,T1)) + ReLU  == per row a dot product with 64 filters
@@ -9,6 +11,7 @@
 // Parameters live in one flat fp32 buffer in the order of the module's parameters():
 //   conv1.weight[64,T1] conv1.bias[64] fc1_adv.weight[512,K1] fc1_adv.bias[512] fc1_val.weight[512,K1]
 //   fc1_val.bias[512] fc2_adv.weight[NA,512] fc2_adv.bias[NA] fc2_val.weight[1,512] fc2_val.bias[1],  K1 = 64*H3.
+#include <cstdlib>
 #include <type_traits>
 
 #include "flm_common.h"
@@ -59,6 +62,7 @@ struct GemmArgs {
                        // selects an independent product: A += group*a_zs, B += group*b_zs, C += group*c_gs
   int groups;
   long c_gs;
+  int x_slowest;       // order in which workgroups are dealt to the XCDs (split-operand kernel): see there
   int b_break_k;       // > 0 (B not k-contiguous only): rows k >= b_break_k of B start b_break_off floats further on
   long b_break_off;    // (two [K/2, N] blocks that are not adjacent in memory multiplied as one [K, N] matrix)
 };
@@ -195,10 +199,299 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmArgs g) {
     }
 }
 
+// ---- the same product on the bf16 matrix cores, fp32 operands split three ways ---------------------------
+// An fp32 number is the exact sum of three bf16 numbers (8 + 8 + 8 significant bits, taken by truncation:
+// hi = top half of the word, mid = top half of x - hi, lo = x - hi - mid).  Of the nine partial products of
+// (a_hi + a_mid + a_lo) * (b_hi + b_mid + b_lo) the six of order 2^-16 and above are accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16; every partial product is exact, and what is left out (a_mid*b_lo, a_lo*b_mid,
+// a_lo*b_lo) is below 2^-21 of the product, 2^-23 on average: the rounding of an fp32 multiply-add.  Six bf16
+// instructions of 32 cycles cover the sixteen k of eight fp32 instructions of 64 cycles.  Infinities and NaNs
+// in the operands give NaN.
+// Workgroup tile 128x128, 4 waves as 2x2, each wave 2x2 tiles of 32x32.  Memory is read 32 k at a time into
+// registers (two fetches in flight), LDS is filled 16 k at a time: a stage holds [split][row][16 k] for both
+// operands, a lane's operand of one instruction is one 16-byte read, rows are 48 bytes apart (an odd number of
+// 16-byte slots: the reads of a 16-lane group fall into 16 different slots).  There are two stages: while the
+// matrix cores work on one, the same wave splits the next 16 k into the other, so its vector instructions run
+// in the shadow of its matrix instructions; one barrier per stage.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define XBK 32                          // k per fetch
+#define XROW 12                         // 32-bit words per LDS row
+#define XSTAGE (3 * 128 * XROW)         // words per operand and stage
+#define X3_LDS_BYTES (2 * 2 * XSTAGE * 4)
+
+// bytes 2,3 of a below bytes 2,3 of b
+__device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+  h = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(h);
+  m = __float_as_uint(r1) & 0xffff0000u;
+  l = __float_as_uint(r1 - __uint_as_float(m));        // at most 8 significant bits are left
+}
+
+// One thread's share of a 128-row x 32-k operand slice: 16 floats as v[q][i].
+// KC (k contiguous): thread (rq = tid >> 2, kq = tid & 3); v[2*half + rep] = row rq + 64*rep, k 16*half + 4*kq + i.
+// otherwise (rows contiguous): thread (rq = tid >> 3, kp = tid & 7); v[2*half + j] = k 16*half + 2*kp + j,
+// rows 4*rq + i.  Either way v[2*half], v[2*half+1] are what the thread adds to the stage of that half.
+// FAST: the slice lies inside the matrix and its rows are 16-byte aligned: no test around any load.
+template <bool KC, bool FAST>
+__device__ __forceinline__ void fetch_x3(const float* __restrict__ P, long ld, int r0, int rmax, int k0, int kmax, bool vec,
+                                         int tid, float (&v)[4][4], int break_k = 0, long break_off = 0) {
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int half = q >> 1, sub = q & 1;
+    int r, k;
+    const float* p;
+    bool ok;
+    if (KC) {
+      r = r0 + (tid >> 2) + 64 * sub;
+      k = k0 + 16 * half + 4 * (tid & 3);
+      p = P + (long)r * ld + k;
+      ok = r < rmax && k + 3 < kmax;
+    } else {
+      k = k0 + 16 * half + 2 * (tid & 7) + sub;
+      r = r0 + 4 * (tid >> 3);
+      p = P + (long)k * ld + r + ((break_k > 0 && k >= break_k) ? break_off : 0);
+      ok = k < kmax && r + 3 < rmax;
+    }
+    if (FAST || (vec && ok)) {
+      const float4 t = *reinterpret_cast<const float4*>(p);
+      v[q][0] = t.x; v[q][1] = t.y; v[q][2] = t.z; v[q][3] = t.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) v[q][i] = (KC ? (r < rmax && k + i < kmax) : (k < kmax && r + i < rmax)) ? p[i] : 0.f;
+    }
+  }
+}
+
+// the thread's two quads of one half, split, into a stage S = [3][128][XROW] words
+template <bool KC>
+__device__ __forceinline__ void place_x3(unsigned* __restrict__ S, int tid, const float (&v0)[4], const float (&v1)[4]) {
+  if (KC) {
+    const int rq = tid >> 2, kq = tid & 3;
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) {
+      const float(&x)[4] = rep ? v1 : v0;
+      unsigned h[4], m[4], l[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) split3(x[i], h[i], m[i], l[i]);
+      unsigned* d = S + (rq + 64 * rep) * XROW + kq * 2;
+      *reinterpret_cast<uint2*>(d) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
+      *reinterpret_cast<uint2*>(d + 128 * XROW) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
+      *reinterpret_cast<uint2*>(d + 2 * 128 * XROW) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
+    }
+  } else {
+    const int rq = tid >> 3, kp = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      unsigned h0, m0, l0, h1, m1, l1;
+      split3(v0[i], h0, m0, l0);
+      split3(v1[i], h1, m1, l1);
+      unsigned* d = S + (4 * rq + i) * XROW + kp;
+      d[0] = pack_hi16(h0, h1);
+      d[128 * XROW] = pack_hi16(m0, m1);
+      d[2 * 128 * XROW] = pack_hi16(l0, l1);
+    }
+  }
+}
+
+// Order of the instructions of one stage, given to the compiler's scheduler: the operand reads first, then per
+// matrix instruction a few of the vector instructions of the split, its LDS writes and (WITH_FETCH) the loads of
+// a later slice in between.
+// end of a stage: the workgroup's barrier, and nothing of the next stage is moved in front of it (its split
+// would otherwise be hoisted to where its loads have not arrived yet)
+__device__ __forceinline__ void stage_end() {
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool WITH_FETCH>
+__device__ __forceinline__ void stage_schedule() {
+  __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);       // LDS reads
+#pragma unroll
+  for (int i = 0; i < 24; i++) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one matrix instruction
+    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);      // vector instructions
+    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // an LDS write
+    if (WITH_FETCH && i >= 8 && i < 16) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a load
+  }
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned x3_lds[];   // [stage][A, B][split][row][XROW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // Workgroups go round-robin to the 8 XCDs, each with an L2 of its own.  The launch index is turned into a
+  // logical one that is consecutive within an XCD, and logical neighbours are the workgroups that read the same
+  // operand tiles: with x_slowest the column tile changes last (few row tiles share a wide B), otherwise the
+  // z index (the K slice) does.
+  unsigned li = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+  if ((nwg & 7) == 0) li = (li & 7) * (nwg >> 3) + (li >> 3);
+  unsigned bx, by, bz;
+  if (g.x_slowest) {
+    by = li % gridDim.y; li /= gridDim.y;
+    bz = li % gridDim.z; bx = li / gridDim.z;
+  } else {
+    bx = li % gridDim.x; li /= gridDim.x;
+    by = li % gridDim.y; bz = li / gridDim.y;
+  }
+  const int m0 = by * GBM, n0 = bx * GBN;
+  const int nks = g.ksplit ? (int)gridDim.z / (g.groups > 1 ? g.groups : 1) : 1;
+  const int grp = g.ksplit ? (int)bz / nks : (int)bz;
+  const int slice = g.ksplit ? (int)bz - grp * nks : 0;
+  const float* A = g.A + (long)grp * g.a_zs;
+  const float* B = g.B + (long)grp * g.b_zs;
+  float* C = g.C + (g.ksplit ? (long)slice * g.c_zs + (long)grp * g.c_gs : (long)grp * g.c_zs);
+  const int k_begin = slice * g.ksplit;
+  const int k_end = g.ksplit ? min(g.K, k_begin + g.ksplit) : g.K;
+  const bool a_vec = (g.lda & 3) == 0 && (reinterpret_cast<size_t>(A) & 15) == 0;
+  const bool b_vec = (g.ldb & 3) == 0 && (reinterpret_cast<size_t>(B) & 15) == 0 && (g.b_break_off & 3) == 0;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int r32 = lane & 31, h4 = (lane >> 5) * 4;
+  // the 16 k of one stage: 12 operand reads, 24 matrix instructions.  The reads stand in front of the split of
+  // the next stage in program order (the compiler cannot tell that the two stages do not overlap), so that
+  // the matrix instructions depend on nothing behind them and can be spread over the split.
+  bf16x8 fa[2][3], fb[2][3];
+  auto operands = [&](int stage) {
+    const unsigned* As = x3_lds + stage * 2 * XSTAGE;
+    const unsigned* Bs = As + XSTAGE;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int s = 0; s < 3; s++) {
+        fa[i][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(As + (s * 128 + wm * 64 + i * 32 + r32) * XROW + h4));
+        fb[i][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bs + (s * 128 + wn * 64 + i * 32 + r32) * XROW + h4));
+      }
+  };
+  auto products = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        f32x16 c = acc[i][j];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
+        acc[i][j] = c;
+      }
+  };
+  auto run = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    const int nf = (k_end - k_begin + XBK - 1) / XBK;          // fetches of 32 k; stages 2f and 2f+1 hold fetch f
+    float a0[4][4], b0[4][4], a1[4][4], b1[4][4];
+    auto fetch = [&](int f, float (&ra)[4][4], float (&rb)[4][4]) {
+      // past the end the last slice is fetched again (FAST has no tests) and never placed
+      const int k0 = k_begin + (FAST ? min(f, nf - 1) : f) * XBK;
+      fetch_x3<A_KC, FAST>(A, g.lda, m0, g.M, k0, k_end, a_vec, tid, ra);
+      fetch_x3<B_KC, FAST>(B, g.ldb, n0, g.N, k0, k_end, b_vec, tid, rb, g.b_break_k, g.b_break_off);
+    };
+    auto place = [&](int stage, int half, const float (&ra)[4][4], const float (&rb)[4][4]) {
+      unsigned* As = x3_lds + stage * 2 * XSTAGE;
+      place_x3<A_KC>(As, tid, ra[2 * half], ra[2 * half + 1]);
+      place_x3<B_KC>(As + XSTAGE, tid, rb[2 * half], rb[2 * half + 1]);
+    };
+    if (nf <= 0) return;
+    fetch(0, a0, b0);
+    fetch(1, a1, b1);
+    place(0, 0, a0, b0);
+    __syncthreads();
+    // Four stages per trip.  At its top a0/b0 hold fetch f, a1/b1 fetch f+1, and stage 0 holds the first half of
+    // fetch f.  A fetch past the end is never multiplied: the trip that would place it is not run.
+    int f = 0;
+    for (; f + 1 < nf; f += 2) {
+      operands(0);
+      place(1, 1, a0, b0);
+      fetch(f + 2, a0, b0);
+      products();
+      stage_schedule<true>();
+      stage_end();
+      operands(1);
+      place(0, 0, a1, b1);
+      products();
+      stage_schedule<false>();
+      stage_end();
+      operands(0);
+      place(1, 1, a1, b1);
+      fetch(f + 3, a1, b1);
+      products();
+      stage_schedule<true>();
+      stage_end();
+      operands(1);
+      place(0, 0, a0, b0);
+      products();
+      stage_schedule<false>();
+      stage_end();
+    }
+    if (f < nf) {      // an odd number of fetches: the last one is in a0/b0, its first half already in stage 0
+      operands(0);
+      place(1, 1, a0, b0);
+      products();
+      __syncthreads();
+      operands(1);
+      products();
+    }
+  };
+  const bool full = a_vec && b_vec && m0 + GBM <= g.M && n0 + GBN <= g.N && ((k_end - k_begin) & (XBK - 1)) == 0;
+  if (full) run(std::true_type{});
+  else run(std::false_type{});
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+      if (n >= g.N) continue;
+      const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= g.M) continue;
+        float v = acc[i][j][r] + bv;
+        long idx;
+        if (EPI == EPI_CONV) {
+          const int b = m / g.H3, h = m - b * g.H3;
+          idx = ((long)b * g.N + n) * g.H3 + h;
+        } else {
+          idx = (long)m * g.ldc + n;
+        }
+        if (g.accumulate) v += C[idx];
+        if (g.relu) v = v > 0.f ? v : 0.f;
+        if (EPI == EPI_MASK) v = g.mask[idx] > 0.f ? v : 0.f;
+        C[idx] = v;
+      }
+    }
+}
+
+// FLM_GEMM=f32 (read once) selects the fp32-instruction kernel: the comparison the split-operand kernel is
+// measured against.
+static bool gemm_use_f32() {
+  static const bool v = [] { const char* e = getenv("FLM_GEMM"); return e && e[0] == 'f'; }();
+  return v;
+}
+
 template <bool A_KC, bool B_KC, int EPI>
 static int launch_gemm(const GemmArgs& g, int nz, hipStream_t stream) {
   dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, nz);
-  hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, EPI>), grid, dim3(256), 0, stream, g);
+  if (gemm_use_f32())
+    hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, EPI>), grid, dim3(256), 0, stream, g);
+  else {
+    static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<A_KC, B_KC, EPI>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES) == hipSuccess;
+    if (!lds_ok) return FLM_E_LAUNCH;
+    hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, EPI>), grid, dim3(256), X3_LDS_BYTES, stream, g);
+  }
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
 }
@@ -973,7 +1266,7 @@ static int dqn_forward_impl(const float* params, const float* x, const uint8_t* 
     // K = 64*H3 is long and M x N small: split K over workgroups, then reduce with bias + ReLU.  Both streams
     // in one launch: group 0 = advantage, group 1 = value (their weight blocks are a fixed stride apart).
     const int nks = fc1_k_slices(B);
-    const int ks = (int)(((L.K1 + nks - 1) / nks + GBK - 1) / GBK * GBK);
+    const int ks = (int)(((L.K1 + nks - 1) / nks + XBK - 1) / XBK * XBK);
     g = GemmArgs{};
     g.A = x1; g.B = params + L.a1_w; g.C = part;
     g.M = B; g.N = 512; g.K = (int)L.K1; g.lda = L.K1; g.ldb = L.K1; g.ldc = 1024;
@@ -1084,7 +1377,7 @@ static int learn_grads_impl(const float* local, const float* target, const float
     GemmArgs g{};
     g.A = dhid; g.B = x1; g.C = grads + L.a1_w;
     g.M = 512; g.N = (int)L.K1; g.K = B; g.lda = 1024; g.ldb = L.K1; g.ldc = L.K1;
-    g.ksplit = B; g.groups = 2; g.a_zs = 512; g.b_zs = 0; g.c_zs = 0; g.c_gs = L.v1_w - L.a1_w;
+    g.ksplit = B; g.groups = 2; g.a_zs = 512; g.b_zs = 0; g.c_zs = 0; g.c_gs = L.v1_w - L.a1_w; g.x_slowest = 1;
     if ((rc = flm::launch_gemm<false, false, flm::EPI_PLAIN>(g, 2, stream))) return rc;
     for (int st = 0; st < 2; st++)
       hipLaunchKernelGGL(flm::colsum_kernel, dim3(8), dim3(1024), 0, stream, dhid + st * 512, B, 512, 1024L,
@@ -1096,7 +1389,7 @@ static int learn_grads_impl(const float* local, const float* target, const float
     GemmArgs g{};
     g.A = dhid; g.B = local + L.a1_w; g.C = dx1; g.mask = x1;
     g.M = B; g.N = (int)L.K1; g.K = 1024; g.lda = 1024; g.ldb = L.K1; g.ldc = L.K1;
-    g.b_break_k = 512; g.b_break_off = (L.v1_w - L.a1_w) - 512L * L.K1;
+    g.b_break_k = 512; g.b_break_off = (L.v1_w - L.a1_w) - 512L * L.K1; g.x_slowest = 1;
     if ((rc = flm::launch_gemm<true, false, flm::EPI_MASK>(g, 1, stream))) return rc;
   }
   // conv weights: per sample dWc_b[64,T1] = dx1_b[64,H3] * s_b[H3,T1], then a fixed-order sum over the batch

@@ -68,6 +68,25 @@ __global__ __launch_bounds__(256) void pat_d(unsigned char* obs, int A, size_t p
   }
 }
 
+// M: like A with 4 KiB tiles (wave w writes agents w, w+16, ..., four 1 KiB rows per plane).  With a plane
+// stride that is a multiple of 32 KiB every chunk a workgroup writes has the same 4 KiB residue mod 8, and that
+// residue is blockIdx.x mod 8 (+ ROT): the XCD the workgroup runs on when workgroups go round-robin to the XCDs.
+template <bool NT, int ROT>
+__global__ __launch_bounds__(1024) void pat_m(unsigned char* obs, int A, size_t ps, size_t ps_used) {
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, e = blockIdx.y;
+  const size_t tile = (blockIdx.x & ~(size_t)7) | ((blockIdx.x + ROT) & 7);
+  const size_t off = tile * 4096 + l * 16;
+  const uint4 v = make_uint4(e, w, l, 1);
+  for (int a = w; a < A; a += 16) {
+    unsigned char* o = obs + ((size_t)e * A + a) * 3 * ps + off;
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+        if (off + c * 1024 < ps_used) st16<NT>(o + p * ps + c * 1024, v);
+  }
+}
+
 // E: linear order, one short-lived workgroup per contiguous chunk of CHUNK bytes
 template <bool NT, int THREADS, int CHUNK>
 __global__ __launch_bounds__(THREADS) void pat_e(unsigned char* obs, size_t n) {
@@ -289,6 +308,82 @@ __global__ __launch_bounds__(256) void pat_l(const short* __restrict__ cols, con
   *reinterpret_cast<uint4*>(obs + ((size_t)agent * 3 + p) * ps + off0 + tid * 16) = v;
 }
 
+// P: persistent linear sweep.  Every wave works through 4 KiB chunks of its XCD's residue class in address
+// order; the inputs of chunk i + D (the agent's column entries, the dense totals) are fetched while chunk i is
+// written, so a read that misses the L2 never stalls a store.  No workgroup barrier.
+template <int D, int VAR>
+__global__ __launch_bounds__(256) void pat_p(const short* __restrict__ cols, const unsigned char* __restrict__ totals,
+                                             int A, int T1, int ps, unsigned char* __restrict__ obs, unsigned n_chunks) {
+  __shared__ __attribute__((aligned(16))) unsigned char tiles[4][4096 + 256];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
+  unsigned char* tile = tiles[wave];
+  const unsigned r = blockIdx.x & 7, q = blockIdx.x >> 3, S = (gridDim.x >> 3) * nwv, s = q * nwv + wave;
+  const unsigned cpp = ps / 4096;
+  const unsigned iters = (n_chunks / 8 + S - 1) / S;
+  int cc[D][3];
+  uint4 tot[D][4];
+  auto fetch = [&](int k, unsigned i) {
+    unsigned J = r + 8 * (s + i * S);
+    if (J >= n_chunks) J = n_chunks - 1;
+    const unsigned P = J / cpp;
+    const unsigned x = J - P * cpp;
+    const unsigned Q = P / 3;
+    const unsigned p = P - Q * 3;
+    const short* ac = cols + (size_t)Q * T1;
+#pragma unroll
+    for (int j = 0; j < 3; j++) cc[k][j] = ac[min(lane + 64 * j, T1 - 1)];
+    const unsigned e = Q / (unsigned)A;
+    const unsigned char* tp = totals + ((size_t)(VAR & 2 ? (e & 7) : e) * 2 + (p == 1 ? 1 : 0)) * ps + x * 4096 + lane * 16;
+#pragma unroll
+    for (int j = 0; j < 4; j++) tot[k][j] = *reinterpret_cast<const uint4*>(tp + j * 1024);
+  };
+#pragma unroll
+  for (int k = 0; k < D; k++) fetch(k, k);
+  for (unsigned i0 = 0; i0 < iters; i0 += D) {
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+      const unsigned i = i0 + k;
+      const unsigned J = r + 8 * (s + i * S);
+      const unsigned P = J / cpp;
+      const unsigned x = J - P * cpp;
+      const unsigned p = P % 3;
+      const int off0 = x * 4096;
+      if (!(VAR & 4)) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) reinterpret_cast<uint4*>(tile)[j * 64 + lane] = make_uint4(0, 0, 0, 0);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int t = lane + 64 * j, c = cc[k][j];
+        const unsigned qq = (unsigned)((c >> 1) * T1 + t - off0);
+        const bool hit = c >= 0 && t < T1 && qq < 4096u;
+        tile[hit ? qq : 4096u + lane] = (c & 1) ? (unsigned char)1 : (unsigned char)0xff;
+      }
+      __builtin_amdgcn_wave_barrier();
+      }
+      uint4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        uint4 mine = make_uint4(cc[k][0], cc[k][1], cc[k][2], 0);
+        if (!(VAR & 4)) mine = reinterpret_cast<const uint4*>(tile)[j * 64 + lane];
+        v[j] = mine;
+        if (p) {
+          const unsigned sh = p == 1 ? 0 : 1;
+          auto f = [sh](unsigned xx) { return sh ? (xx >> 1) & 0x01010101u : xx & ~(xx >> 1) & 0x01010101u; };
+          v[j] = make_uint4(tot[k][j].x - f(mine.x), tot[k][j].y - f(mine.y), tot[k][j].z - f(mine.z), tot[k][j].w - f(mine.w));
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (J < n_chunks) {
+        unsigned char* o = obs + (size_t)J * 4096 + lane * 16;
+#pragma unroll
+        for (int j = 0; j < 4; j++) *reinterpret_cast<uint4*>(o + j * 1024) = v[j];
+      }
+      fetch(k, i + D);
+    }
+  }
+}
+
 #define CK(x) do { hipError_t r = (x); if (r != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(r)); return 1; } } while (0)
 
 template <class F>
@@ -341,6 +436,24 @@ int main(int argc, char** argv) {
   timeit("G same residue, 150 iters", [&] { pat_g<150><<<(nch / 150 + 7) / 8 * 8, 256>>>(obs, n); }, bytes);
   timeit("H changing residue, 150 iters", [&] { pat_h<150><<<(nch / 150 + 7) / 8 * 8, 256>>>(obs, n); }, bytes);
   timeit("G same residue, 38 iters", [&] { pat_g<38><<<(nch / 38 + 7) / 8 * 8, 256>>>(obs, n); }, bytes);
+  if (argc > 2 && argv[2][0] == 'a') {   // residue-aligned plane hopping: stride 98304 = 3 * 32 KiB, 88,184 bytes of each plane written
+    CK(hipFree(obs));
+    const size_t psa = 98304, used = 88192;
+    const size_t na = (size_t)E * A * 3 * psa;
+    CK(hipMalloc(&obs, na));
+    printf("obs %p\n", (void*)obs);
+    const double bu = (double)E * A * 3 * used;
+    dim3 gm(psa / 4096, E), gm2((used + 4095) / 4096, E);
+    timeit("M aligned, residue = xcd, NT", [&] { pat_m<true, 0><<<gm, 1024>>>(obs, A, psa, used); }, bu);
+    timeit("M aligned, residue = xcd", [&] { pat_m<false, 0><<<gm, 1024>>>(obs, A, psa, used); }, bu);
+    timeit("M aligned, residue = xcd+1", [&] { pat_m<false, 1><<<gm, 1024>>>(obs, A, psa, used); }, bu);
+    timeit("M aligned, residue = xcd+2", [&] { pat_m<false, 2><<<gm, 1024>>>(obs, A, psa, used); }, bu);
+    timeit("M aligned, residue = xcd+4", [&] { pat_m<false, 4><<<gm, 1024>>>(obs, A, psa, used); }, bu);
+    timeit("M aligned, 22 tiles per env", [&] { pat_m<false, 0><<<gm2, 1024>>>(obs, A, psa, used); }, bu);
+    timeit("M stride 88320 (unaligned)", [&] { pat_m<false, 0><<<gm2, 1024>>>(obs, A, 88320, used); }, bu);
+    CK(hipFree(obs));
+    return 0;
+  }
   short* cols;
   uint4* totals;
   CK(hipMalloc(&cols, 4096 * 151 * 2));
@@ -382,6 +495,23 @@ int main(int argc, char** argv) {
     timeit("K hoisted loads, 64thr, 1-D", [&] { pat_k<64, false><<<g1, 64>>>(cols2, tot2, A, T1, ps2, obs2); }, by2);
     timeit("K 64thr, 3-D, skip empty", [&] { pat_k<64, true, true><<<g3, 64>>>(cols2, tot2, A, T1, ps2, obs2); }, by2);
     timeit("K 128thr, 3-D, skip empty", [&] { pat_k<128, true, true><<<g3, 128>>>(cols2, tot2, A, T1, ps2, obs2); }, by2);
+    if (argc > 2 && argv[2][0] == 'p') {
+      const unsigned nc = (unsigned)(n2 / 4096);
+      timeit("P persistent D=2, 512 wg", [&] { pat_p<2, 0><<<512, 256>>>(cols2, tot2, A, T1, ps2, obs2, nc); }, by2);
+      timeit("P persistent D=4, 512 wg", [&] { pat_p<4, 0><<<512, 256>>>(cols2, tot2, A, T1, ps2, obs2, nc); }, by2);
+      timeit("P persistent D=4, 1024 wg", [&] { pat_p<4, 0><<<1024, 256>>>(cols2, tot2, A, T1, ps2, obs2, nc); }, by2);
+      timeit("P persistent D=4, 2048 wg", [&] { pat_p<4, 0><<<2048, 256>>>(cols2, tot2, A, T1, ps2, obs2, nc); }, by2);
+      timeit("P persistent D=8, 512 wg", [&] { pat_p<8, 0><<<512, 256>>>(cols2, tot2, A, T1, ps2, obs2, nc); }, by2);
+      timeit("P persistent D=8, 1024 wg", [&] { pat_p<8, 0><<<1024, 256>>>(cols2, tot2, A, T1, ps2, obs2, nc); }, by2);
+      timeit("P D=4, 1024 wg, totals small", [&] { pat_p<4, 2><<<1024, 256>>>(cols2, tot2, A, T1, ps2, obs2, nc); }, by2);
+      timeit("P D=4, 1024 wg, no LDS", [&] { pat_p<4, 4><<<1024, 256>>>(cols2, tot2, A, T1, ps2, obs2, nc); }, by2);
+      timeit("P D=4, 1024 wg, no LDS, totals small", [&] { pat_p<4, 6><<<1024, 256>>>(cols2, tot2, A, T1, ps2, obs2, nc); }, by2);
+      timeit("P D=4, 1024 wg x 64 thr", [&] { pat_p<4, 0><<<1024, 64>>>(cols2, tot2, A, T1, ps2, obs2, nc); }, by2);
+      timeit("P D=4, 4096 wg x 64 thr", [&] { pat_p<4, 0><<<4096, 64>>>(cols2, tot2, A, T1, ps2, obs2, nc); }, by2);
+      timeit("P D=4, 8192 wg x 64 thr", [&] { pat_p<4, 0><<<8192, 64>>>(cols2, tot2, A, T1, ps2, obs2, nc); }, by2);
+      timeit("L lean, 1-D", [&] { pat_l<false><<<g1, 256>>>(cols2, tot2, A, T1, ps2, obs2); }, by2);
+      return 0;
+    }
     timeit("L lean, 3-D", [&] { pat_l<true><<<g3, 256>>>(cols2, tot2, A, T1, ps2, obs2); }, by2);
     timeit("L lean, 1-D, cols small", [&] { pat_l<false, 1><<<g1, 256>>>(cols2, tot2, A, T1, ps2, obs2); }, by2);
     timeit("L lean, 1-D, totals small", [&] { pat_l<false, 2><<<g1, 256>>>(cols2, tot2, A, T1, ps2, obs2); }, by2);
