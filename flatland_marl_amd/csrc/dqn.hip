@@ -229,75 +229,75 @@ __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsign
   l = __float_as_uint(r1 - __uint_as_float(m));        // at most 8 significant bits are left
 }
 
-// One thread's share of a 128-row x 32-k operand slice: 16 floats as v[q][i].
-// KC (k contiguous): thread (rq = tid >> 2, kq = tid & 3); v[2*half + rep] = row rq + 64*rep, k 16*half + 4*kq + i.
-// otherwise (rows contiguous): thread (rq = tid >> 3, kp = tid & 7); v[2*half + j] = k 16*half + 2*kp + j,
-// rows 4*rq + i.  Either way v[2*half], v[2*half+1] are what the thread adds to the stage of that half.
+// One thread's share of a 128-row x 32-k operand slice: 8 floats, v[half] the four of one stage.  512 threads.
+// KC (k contiguous): thread (row = tid >> 2, kq = tid & 3); v[half][i] = row, k 16*half + 4*kq + i.
+// otherwise (rows contiguous): thread (rq = tid >> 4, k16 = tid & 15); v[half][i] = k 16*half + k16, row 4*rq + i.
 // FAST: the slice lies inside the matrix and its rows are 16-byte aligned: no test around any load.
 template <bool KC, bool FAST>
 __device__ __forceinline__ void fetch_x3(const float* __restrict__ P, long ld, int r0, int rmax, int k0, int kmax, bool vec,
-                                         int tid, float (&v)[4][4], int break_k = 0, long break_off = 0) {
+                                         int tid, float (&v)[2][4], int break_k = 0, long break_off = 0) {
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int half = q >> 1, sub = q & 1;
+  for (int half = 0; half < 2; half++) {
     int r, k;
     const float* p;
     bool ok;
     if (KC) {
-      r = r0 + (tid >> 2) + 64 * sub;
+      r = r0 + (tid >> 2);
       k = k0 + 16 * half + 4 * (tid & 3);
       p = P + (long)r * ld + k;
       ok = r < rmax && k + 3 < kmax;
     } else {
-      k = k0 + 16 * half + 2 * (tid & 7) + sub;
-      r = r0 + 4 * (tid >> 3);
+      r = r0 + 4 * (tid >> 4);
+      k = k0 + 16 * half + (tid & 15);
       p = P + (long)k * ld + r + ((break_k > 0 && k >= break_k) ? break_off : 0);
       ok = k < kmax && r + 3 < rmax;
     }
     if (FAST || (vec && ok)) {
       const float4 t = *reinterpret_cast<const float4*>(p);
-      v[q][0] = t.x; v[q][1] = t.y; v[q][2] = t.z; v[q][3] = t.w;
+      v[half][0] = t.x; v[half][1] = t.y; v[half][2] = t.z; v[half][3] = t.w;
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; i++) v[q][i] = (KC ? (r < rmax && k + i < kmax) : (k < kmax && r + i < rmax)) ? p[i] : 0.f;
+      for (int i = 0; i < 4; i++) v[half][i] = (KC ? (r < rmax && k + i < kmax) : (k < kmax && r + i < rmax)) ? p[i] : 0.f;
     }
   }
 }
 
-// the thread's two quads of one half, split, into a stage S = [3][128][XROW] words
+// value of the neighbouring lane (lane ^ 1)
+__device__ __forceinline__ float from_pair_lane(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+}
+
+// the thread's four floats of one half, split, into a stage S = [3][128][XROW] words
 template <bool KC>
-__device__ __forceinline__ void place_x3(unsigned* __restrict__ S, int tid, const float (&v0)[4], const float (&v1)[4]) {
+__device__ __forceinline__ void place_x3(unsigned* __restrict__ S, int tid, const float (&x)[4]) {
   if (KC) {
-    const int rq = tid >> 2, kq = tid & 3;
+    unsigned h[4], m[4], l[4];
 #pragma unroll
-    for (int rep = 0; rep < 2; rep++) {
-      const float(&x)[4] = rep ? v1 : v0;
-      unsigned h[4], m[4], l[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) split3(x[i], h[i], m[i], l[i]);
-      unsigned* d = S + (rq + 64 * rep) * XROW + kq * 2;
-      *reinterpret_cast<uint2*>(d) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
-      *reinterpret_cast<uint2*>(d + 128 * XROW) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
-      *reinterpret_cast<uint2*>(d + 2 * 128 * XROW) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
-    }
+    for (int i = 0; i < 4; i++) split3(x[i], h[i], m[i], l[i]);
+    unsigned* d = S + (tid >> 2) * XROW + (tid & 3) * 2;
+    *reinterpret_cast<uint2*>(d) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
+    *reinterpret_cast<uint2*>(d + 128 * XROW) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
+    *reinterpret_cast<uint2*>(d + 2 * 128 * XROW) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
   } else {
-    const int rq = tid >> 3, kp = tid & 7;
+    // Two neighbouring lanes hold the same four rows at an even and an odd k.  They swap halves: the even lane
+    // ends up with both k of rows 0 and 1, the odd lane with both k of rows 2 and 3, and each writes whole words.
+    const bool even = (tid & 1) == 0;
+    const float g0 = from_pair_lane(even ? x[2] : x[0]), g1 = from_pair_lane(even ? x[3] : x[1]);
+    const float ke[2] = {even ? x[0] : g0, even ? x[1] : g1};      // the even k of this lane's two rows
+    const float ko[2] = {even ? g0 : x[2], even ? g1 : x[3]};      // the odd k
+    unsigned* d = S + (4 * (tid >> 4) + (even ? 0 : 2)) * XROW + ((tid & 15) >> 1);
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < 2; i++) {
       unsigned h0, m0, l0, h1, m1, l1;
-      split3(v0[i], h0, m0, l0);
-      split3(v1[i], h1, m1, l1);
-      unsigned* d = S + (4 * rq + i) * XROW + kp;
-      d[0] = pack_hi16(h0, h1);
-      d[128 * XROW] = pack_hi16(m0, m1);
-      d[2 * 128 * XROW] = pack_hi16(l0, l1);
+      split3(ke[i], h0, m0, l0);
+      split3(ko[i], h1, m1, l1);
+      d[i * XROW] = pack_hi16(h0, h1);
+      d[i * XROW + 128 * XROW] = pack_hi16(m0, m1);
+      d[i * XROW + 2 * 128 * XROW] = pack_hi16(l0, l1);
     }
   }
 }
 
-// Order of the instructions of one stage, given to the compiler's scheduler: the operand reads first, then per
-// matrix instruction a few of the vector instructions of the split, its LDS writes and (WITH_FETCH) the loads of
-// a later slice in between.
 // end of a stage: the workgroup's barrier, and nothing of the next stage is moved in front of it (its split
 // would otherwise be hoisted to where its loads have not arrived yet)
 __device__ __forceinline__ void stage_end() {
@@ -306,23 +306,26 @@ __device__ __forceinline__ void stage_end() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// Order of the instructions of one stage, given to the compiler's scheduler: the operand reads first, then per
+// matrix instruction a few of the vector instructions of the split, its LDS writes and (WITH_FETCH) the loads of
+// a later slice in between.
 template <bool WITH_FETCH>
 __device__ __forceinline__ void stage_schedule() {
-  __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);       // LDS reads
+  __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);        // LDS reads
 #pragma unroll
-  for (int i = 0; i < 24; i++) {
+  for (int i = 0; i < 12; i++) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one matrix instruction
-    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);      // vector instructions
+    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);      // vector instructions
     __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // an LDS write
-    if (WITH_FETCH && i >= 8 && i < 16) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a load
+    if (WITH_FETCH && i >= 4 && i < 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a load
   }
 }
 
 template <bool A_KC, bool B_KC, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
+__global__ __launch_bounds__(512, 4) void gemm_x3_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned x3_lds[];   // [stage][A, B][split][row][XROW]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave >> 2, wn = wave & 3;                 // 8 waves as 2 x 4, each 2 x 1 tiles of 32 x 32
   // Workgroups go round-robin to the 8 XCDs, each with an L2 of its own.  The launch index is turned into a
   // logical one that is consecutive within an XCD, and logical neighbours are the workgroups that read the same
   // operand tiles: with x_slowest the column tile changes last (few row tiles share a wide B), otherwise the
@@ -349,59 +352,55 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
   const int k_end = g.ksplit ? min(g.K, k_begin + g.ksplit) : g.K;
   const bool a_vec = (g.lda & 3) == 0 && (reinterpret_cast<size_t>(A) & 15) == 0;
   const bool b_vec = (g.ldb & 3) == 0 && (reinterpret_cast<size_t>(B) & 15) == 0 && (g.b_break_off & 3) == 0;
-  f32x16 acc[2][2];
+  f32x16 acc[2];
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
 
   const int r32 = lane & 31, h4 = (lane >> 5) * 4;
-  // the 16 k of one stage: 12 operand reads, 24 matrix instructions.  The reads stand in front of the split of
+  // the 16 k of one stage: 9 operand reads, 12 matrix instructions.  The reads stand in front of the split of
   // the next stage in program order (the compiler cannot tell that the two stages do not overlap), so that
   // the matrix instructions depend on nothing behind them and can be spread over the split.
-  bf16x8 fa[2][3], fb[2][3];
+  bf16x8 fa[2][3], fb[3];
   auto operands = [&](int stage) {
     const unsigned* As = x3_lds + stage * 2 * XSTAGE;
     const unsigned* Bs = As + XSTAGE;
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int s = 0; s < 3; s++) {
+      fb[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bs + (s * 128 + wn * 32 + r32) * XROW + h4));
 #pragma unroll
-      for (int s = 0; s < 3; s++) {
+      for (int i = 0; i < 2; i++)
         fa[i][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(As + (s * 128 + wm * 64 + i * 32 + r32) * XROW + h4));
-        fb[i][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bs + (s * 128 + wn * 64 + i * 32 + r32) * XROW + h4));
-      }
+    }
   };
   auto products = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        f32x16 c = acc[i][j];
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
-        acc[i][j] = c;
-      }
+    for (int i = 0; i < 2; i++) {
+      f32x16 c = acc[i];
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[2], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[0], c, 0, 0, 0);
+      acc[i] = c;
+    }
   };
   auto run = [&](auto fast_tag) {
     constexpr bool FAST = decltype(fast_tag)::value;
     const int nf = (k_end - k_begin + XBK - 1) / XBK;          // fetches of 32 k; stages 2f and 2f+1 hold fetch f
-    float a0[4][4], b0[4][4], a1[4][4], b1[4][4];
-    auto fetch = [&](int f, float (&ra)[4][4], float (&rb)[4][4]) {
+    float a0[2][4], b0[2][4], a1[2][4], b1[2][4];
+    auto fetch = [&](int f, float (&ra)[2][4], float (&rb)[2][4]) {
       // past the end the last slice is fetched again (FAST has no tests) and never placed
       const int k0 = k_begin + (FAST ? min(f, nf - 1) : f) * XBK;
       fetch_x3<A_KC, FAST>(A, g.lda, m0, g.M, k0, k_end, a_vec, tid, ra);
       fetch_x3<B_KC, FAST>(B, g.ldb, n0, g.N, k0, k_end, b_vec, tid, rb, g.b_break_k, g.b_break_off);
     };
-    auto place = [&](int stage, int half, const float (&ra)[4][4], const float (&rb)[4][4]) {
+    auto place = [&](int stage, int half, const float (&ra)[2][4], const float (&rb)[2][4]) {
       unsigned* As = x3_lds + stage * 2 * XSTAGE;
-      place_x3<A_KC>(As, tid, ra[2 * half], ra[2 * half + 1]);
-      place_x3<B_KC>(As + XSTAGE, tid, rb[2 * half], rb[2 * half + 1]);
+      place_x3<A_KC>(As, tid, ra[half]);
+      place_x3<B_KC>(As + XSTAGE, tid, rb[half]);
     };
     if (nf <= 0) return;
     fetch(0, a0, b0);
@@ -447,31 +446,31 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
   const bool full = a_vec && b_vec && m0 + GBM <= g.M && n0 + GBN <= g.N && ((k_end - k_begin) & (XBK - 1)) == 0;
   if (full) run(std::true_type{});
   else run(std::false_type{});
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int n = n0 + wn * 64 + j * 32 + (lane & 31);
-      if (n >= g.N) continue;
+  {
+    const int n = n0 + wn * 32 + (lane & 31);
+    if (n < g.N) {
       const float bv = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m >= g.M) continue;
-        float v = acc[i][j][r] + bv;
-        long idx;
-        if (EPI == EPI_CONV) {
-          const int b = m / g.H3, h = m - b * g.H3;
-          idx = ((long)b * g.N + n) * g.H3 + h;
-        } else {
-          idx = (long)m * g.ldc + n;
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (m >= g.M) continue;
+          float v = acc[i][r] + bv;
+          long idx;
+          if (EPI == EPI_CONV) {
+            const int b = m / g.H3, h = m - b * g.H3;
+            idx = ((long)b * g.N + n) * g.H3 + h;
+          } else {
+            idx = (long)m * g.ldc + n;
+          }
+          if (g.accumulate) v += C[idx];
+          if (g.relu) v = v > 0.f ? v : 0.f;
+          if (EPI == EPI_MASK) v = g.mask[idx] > 0.f ? v : 0.f;
+          C[idx] = v;
         }
-        if (g.accumulate) v += C[idx];
-        if (g.relu) v = v > 0.f ? v : 0.f;
-        if (EPI == EPI_MASK) v = g.mask[idx] > 0.f ? v : 0.f;
-        C[idx] = v;
-      }
     }
+  }
 }
 
 // FLM_GEMM=f32 (read once) selects the fp32-instruction kernel: the comparison the split-operand kernel is
@@ -490,7 +489,7 @@ static int launch_gemm(const GemmArgs& g, int nz, hipStream_t stream) {
     static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<A_KC, B_KC, EPI>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES) == hipSuccess;
     if (!lds_ok) return FLM_E_LAUNCH;
-    hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, EPI>), grid, dim3(256), X3_LDS_BYTES, stream, g);
+    hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, EPI>), grid, dim3(512), X3_LDS_BYTES, stream, g);
   }
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
