@@ -1182,12 +1182,12 @@ static int launch_conv_u8(const uint8_t* obs_u8, const float* Wc, const float* b
 
 }  // namespace flm
 
-// K slices of the first dense layer (advantage and value streams side by side: 8 column tiles): enough of
-// them that the launch has several workgroups per CU, which is what keeps the matrix pipes busy across the
-// barriers of the single-buffered K loop.
+// K slices of the first dense layer (advantage and value streams side by side: 8 column tiles).  Two
+// workgroups of the split-operand kernel fit a CU, 512 on the chip: the slices are chosen so that the launch is
+// as close to a whole number of such rounds as the tiles allow (a launch of one and a half rounds takes two).
 static int fc1_k_slices(int B) {
   const long tiles = (long)((B + GBM - 1) / GBM) * 8;
-  long n = (768 + tiles - 1) / tiles;
+  long n = tiles >= 512 ? 1 : 512 / tiles;
   if (n < 1) n = 1;
   if (n > 32) n = 32;
   return (int)n;
