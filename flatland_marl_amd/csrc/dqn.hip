@@ -40,10 +40,10 @@ struct DqnLayout {
   }
 };
 
-// ---- tiled fp32 MFMA GEMM ---------------------------------------------------------------------------
+// ---- tiled matrix product ---------------------------------------------------------------------------
 // C[M,N] (+)= A[M,K] * B[K,N].  A is addressed A[m*lda + k] when A_KC (k contiguous) else A[k*lda + m];
-// B is B[n*ldb + k] when B_KC else B[k*ldb + n].  Workgroup tile 128x128x16, 4 waves as 2x2, each wave
-// 2x2 MFMA tiles of 32x32.  blockIdx.z selects a batch / K-slice through the z strides.
+// B is B[n*ldb + k] when B_KC else B[k*ldb + n].  Workgroup tile 128x128.  The z index of the grid selects a
+// batch / K-slice through the z strides.
 enum { EPI_PLAIN = 0, EPI_CONV = 1, EPI_MASK = 2 };
 
 struct GemmArgs {
@@ -69,137 +69,8 @@ struct GemmArgs {
 
 #define GBM 128
 #define GBN 128
-#define GBK 16
-#define APAD 2   // k-contiguous sources are transposed on the way into LDS; this pad spreads the 4 k-groups over banks
-#define BPAD 4
 
-// Global -> register fetch of one operand tile slice owned by a thread (2 x 4 floats), and its placement in LDS.
-// KC: the source is k-contiguous (thread reads 4 consecutive k of one row, stored transposed);
-// otherwise the source is m/n-contiguous (thread reads 4 consecutive rows of one k).
-template <bool KC>
-__device__ __forceinline__ void fetch_tile(const float* __restrict__ P, long ld, int r0, int rmax, int k0, int kmax, bool vec,
-                                           int tid, float (&v)[2][4], int break_k = 0, long break_off = 0) {
-#pragma unroll
-  for (int rep = 0; rep < 2; rep++) {
-    if (KC) {
-      const int r = r0 + (tid >> 2) + rep * 64, k = k0 + (tid & 3) * 4;
-      const float* p = P + (long)r * ld + k;
-      if (vec && r < rmax && k + 3 < kmax) {
-        const float4 t = *reinterpret_cast<const float4*>(p);
-        v[rep][0] = t.x; v[rep][1] = t.y; v[rep][2] = t.z; v[rep][3] = t.w;
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; i++) v[rep][i] = (r < rmax && k + i < kmax) ? p[i] : 0.f;
-      }
-    } else {
-      const int k = k0 + (tid >> 5) + rep * 8, r = r0 + (tid & 31) * 4;
-      const float* p = P + (long)k * ld + r + ((break_k > 0 && k >= break_k) ? break_off : 0);
-      if (vec && k < kmax && r + 3 < rmax) {
-        const float4 t = *reinterpret_cast<const float4*>(p);
-        v[rep][0] = t.x; v[rep][1] = t.y; v[rep][2] = t.z; v[rep][3] = t.w;
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; i++) v[rep][i] = (k < kmax && r + i < rmax) ? p[i] : 0.f;
-      }
-    }
-  }
-}
-
-template <bool KC>
-__device__ __forceinline__ void place_tile(float (*S)[GBM + BPAD + APAD], int tid, const float (&v)[2][4]) {
-#pragma unroll
-  for (int rep = 0; rep < 2; rep++) {
-    if (KC) {
-      const int r = (tid >> 2) + rep * 64, k4 = (tid & 3) * 4;
-#pragma unroll
-      for (int i = 0; i < 4; i++) S[k4 + i][r] = v[rep][i];
-    } else {
-      const int k = (tid >> 5) + rep * 8, r4 = (tid & 31) * 4;
-#pragma unroll
-      for (int i = 0; i < 4; i++) S[k][r4 + i] = v[rep][i];
-    }
-  }
-}
-
-template <bool A_KC, bool B_KC, int EPI>
-__global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float As[GBK][GBM + BPAD + APAD];
-  __shared__ __attribute__((aligned(16))) float Bs[GBK][GBN + BPAD + APAD];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
-  const int nks = g.ksplit ? (int)gridDim.z / (g.groups > 1 ? g.groups : 1) : 1;
-  const int grp = g.ksplit ? (int)blockIdx.z / nks : (int)blockIdx.z;
-  const int slice = g.ksplit ? (int)blockIdx.z - grp * nks : 0;
-  const float* A = g.A + (long)grp * g.a_zs;
-  const float* B = g.B + (long)grp * g.b_zs;
-  float* C = g.C + (g.ksplit ? (long)slice * g.c_zs + (long)grp * g.c_gs : (long)grp * g.c_zs);
-  const int k_begin = slice * g.ksplit;
-  const int k_end = g.ksplit ? min(g.K, k_begin + g.ksplit) : g.K;
-  // 16-byte fetches need the rows 16-byte aligned
-  const bool a_vec = (g.lda & 3) == 0 && (reinterpret_cast<size_t>(A) & 15) == 0;
-  const bool b_vec = (g.ldb & 3) == 0 && (reinterpret_cast<size_t>(B) & 15) == 0 && (g.b_break_off & 3) == 0;
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-  // software pipeline: the next K slice is fetched into registers while the matrix cores work on the one in LDS
-  float ra[2][4], rb[2][4];
-  fetch_tile<A_KC>(A, g.lda, m0, g.M, k_begin, k_end, a_vec, tid, ra);
-  fetch_tile<B_KC>(B, g.ldb, n0, g.N, k_begin, k_end, b_vec, tid, rb, g.b_break_k, g.b_break_off);
-  for (int k0 = k_begin; k0 < k_end; k0 += GBK) {
-    place_tile<A_KC>(As, tid, ra);
-    place_tile<B_KC>(Bs, tid, rb);
-    __syncthreads();
-    if (k0 + GBK < k_end) {
-      fetch_tile<A_KC>(A, g.lda, m0, g.M, k0 + GBK, k_end, a_vec, tid, ra);
-      fetch_tile<B_KC>(B, g.ldb, n0, g.N, k0 + GBK, k_end, b_vec, tid, rb, g.b_break_k, g.b_break_off);
-    }
-#pragma unroll
-    for (int kk = 0; kk < GBK; kk += 2) {
-      const int kr = kk + (lane >> 5), c = lane & 31;
-      const float a0 = As[kr][wm * 64 + c], a1 = As[kr][wm * 64 + 32 + c];
-      const float b0 = Bs[kr][wn * 64 + c], b1 = Bs[kr][wn * 64 + 32 + c];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  // ---- epilogue: accumulator element r of tile (i,j) is row (r&3)+8*(r>>2)+4*(lane>>5), column lane&31
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int n = n0 + wn * 64 + j * 32 + (lane & 31);
-      if (n >= g.N) continue;
-      const float bv = g.bias ? g.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m >= g.M) continue;
-        float v = acc[i][j][r] + bv;
-        long idx;
-        if (EPI == EPI_CONV) {
-          const int b = m / g.H3, h = m - b * g.H3;
-          idx = ((long)b * g.N + n) * g.H3 + h;
-        } else {
-          idx = (long)m * g.ldc + n;
-        }
-        if (g.accumulate) v += C[idx];
-        if (g.relu) v = v > 0.f ? v : 0.f;
-        if (EPI == EPI_MASK) v = g.mask[idx] > 0.f ? v : 0.f;
-        C[idx] = v;
-      }
-    }
-}
-
-// ---- the same product on the bf16 matrix cores, fp32 operands split three ways ---------------------------
+// ---- the product on the bf16 matrix cores, fp32 operands split three ways -----------------------------------
 // An fp32 number is the exact sum of three bf16 numbers (8 + 8 + 8 significant bits, taken by truncation:
 // hi = top half of the word, mid = top half of x - hi, lo = x - hi - mid).  Of the nine partial products of
 // (a_hi + a_mid + a_lo) * (b_hi + b_mid + b_lo) the six of order 2^-16 and above are accumulated in fp32 by
@@ -473,19 +344,10 @@ __global__ __launch_bounds__(512, 4) void gemm_x3_kernel(GemmArgs g) {
   }
 }
 
-// FLM_GEMM=f32 (read once) selects the fp32-instruction kernel: the comparison the split-operand kernel is
-// measured against.
-static bool gemm_use_f32() {
-  static const bool v = [] { const char* e = getenv("FLM_GEMM"); return e && e[0] == 'f'; }();
-  return v;
-}
-
 template <bool A_KC, bool B_KC, int EPI>
 static int launch_gemm(const GemmArgs& g, int nz, hipStream_t stream) {
   dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, nz);
-  if (gemm_use_f32())
-    hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, EPI>), grid, dim3(256), 0, stream, g);
-  else {
+  {
     static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<A_KC, B_KC, EPI>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES) == hipSuccess;
     if (!lds_ok) return FLM_E_LAUNCH;

@@ -1,5 +1,5 @@
 """Drop-in for the reference's Dueling_DQN (src/model.py:11-43): same constructor, same state_dict keys
-and shapes, same default initialisation; forward runs the hand-written fp32 MFMA kernels (no autograd)."""
+and shapes, same default initialisation; forward runs the hand-written matrix-core kernels (fp32 values, no autograd)."""
 import torch
 import torch.nn as nn
 

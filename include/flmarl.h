@@ -368,7 +368,8 @@ int flm_env_step(const uint16_t* grid, const int32_t* action, const int32_t* ini
                  int32_t* malfunction, int32_t* malfunction_moving, const uint32_t* env_seed,
                  uint32_t malfunction_threshold, int min_duration, int max_duration, int step_index, void* stream);
 
-/* ---- Dueling Double-DQN (fp32; matrix products on the fp32 MFMA) -------------------------------------
+/* ---- Dueling Double-DQN (fp32 values and accumulation; matrix products on the matrix cores, the large ones with
+ * every fp32 operand split into three bf16 terms: accuracy of an fp32 multiply-add, Inf/NaN operands give NaN) -------------------------------------
  * Replaces Dueling_DQN.forward, src/model.py:31-43, and the numeric part of DQNAgent.act / learn /
  * soft_update, src/agent.py:69-131.  H3 = 3*max_rails input rows, T1 = depth+1 columns, NA = number of
  * actions (the reference's action_space; src/main.py:92 uses 2), 1 <= NA <= FLM_DQN_MAX_ACTIONS.

@@ -250,6 +250,33 @@ def test_small_batch_forward_vs_torch(H3, T1):
         assert close(got, want), B
 
 
+@pytest.mark.parametrize("B,H3,T1", [(64, 30, 40), (200, 45, 151)])
+def test_forward_wide_dynamic_range_vs_float64(B, H3, T1):
+    """The matrix products split every fp32 operand into three bf16 terms and leave out the partial products below
+    2^-21 of a product.  With inputs and weights spread over sixteen binary orders of magnitude the Q-values must
+    stay as close to the float64 result as PyTorch's own fp32 forward pass does (within a factor of four of its
+    error, plus 1e-6 of the largest |Q|)."""
+    from flatland_marl_amd.model import Dueling_DQN
+    from tests.torch_ref_dqn import TorchDuelingDQN
+    torch.manual_seed(B + H3)
+    net = Dueling_DQN(T1, H3, 2)
+    g = torch.Generator().manual_seed(7 * B + T1)
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.mul_(torch.exp2(torch.randint(-12, 5, p_.shape, generator=g).float()))
+    ref32 = TorchDuelingDQN(T1, H3)
+    ref32.load_state_dict(net.state_dict())
+    ref64 = copy.deepcopy(ref32).double()
+    x = torch.randn(B, 1, H3, T1, generator=g) * torch.exp2(torch.randint(-10, 7, (B, 1, H3, T1), generator=g).float())
+    q64 = ref64(x.double()).detach().numpy()
+    q32 = ref32(x).detach().numpy().astype(np.float64)
+    got = net.to("cuda")(x).cpu().numpy().astype(np.float64)
+    scale = np.abs(q64).max()
+    err32, err = np.abs(q32 - q64).max(), np.abs(got - q64).max()
+    assert np.isfinite(got).all()
+    assert err <= 4 * err32 + 1e-6 * scale, (err, err32, scale)
+
+
 @pytest.mark.parametrize("B,Rp,T1,pad", [(5, 10, 21, 0), (300, 7, 151, 3), (33, 4, 301, 1), (700, 100, 151, 0)])
 def test_forward_from_uint8_observations_vs_torch(B, Rp, T1, pad):
     """The byte-input forward (convolution reads int8 / uint8 planes) against plain PyTorch fp32 on the same values;

@@ -4,7 +4,7 @@
 # Every pass is its own run with its own time limit; the script stops at the first failure.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/prof_c
+O=gpurun_out/prof_c; rm -rf $O
 mkdir -p $O
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $O/bench -o bench --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-rollout > $O/bench.log 2>&1
 echo "bench stats done"
