@@ -840,7 +840,15 @@ __global__ void obs_to_f32_kernel(const uint8_t* __restrict__ obs, int n, int Rp
 //   * multiplies filters (matrix rows) by observation rows (matrix columns) on the matrix cores, 2x2 tiles of
 //     32x32: a lane then holds 32 filters of one observation row, and a store instruction writes 32
 //     consecutive rows of one filter, which is the layout of x1.
+// BF: the products run on the bf16 matrix cores.  An observation byte (-1..1 or a count below 255) is exact in
+// bf16, and a filter weight is the exact sum of three bf16 terms (split3), so w*x is the sum of three exact partial
+// products accumulated in fp32: three v_mfma_f32_32x32x16_bf16 of 32 cycles cover the sixteen k of eight fp32
+// instructions of 64.  The filter bank is staged split as [term][filter][k] with k contiguous (a lane's operand is
+// one 16-byte read; rows an odd number of 16-byte slots apart), a lane's eight bytes of an observation row are
+// cut out of three aligned words (the row keeps its byte offset) and turned into bf16 in registers.
 #define CV_TILE 64
+#define CV_KP16(T1) (((T1) + 15) & ~15)                         // K padded to whole bf16 instructions
+#define CV_BROW(T1) (2 * CV_KP16(T1) + 16)                      // bytes per filter and term in LDS
 #define CV_ASTRIDE(T1) ((((T1) + 6) / 4 * 4) | 4)              // bytes per row in LDS: covers 3 + T1 bytes, word count odd
 #define CV_WSTRIDE 65                                            // floats per k in LDS
 __device__ __forceinline__ void cv_wave_sync() {
@@ -849,7 +857,19 @@ __device__ __forceinline__ void cv_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 }
 
-template <int WPL, int NWAVE>   // words a lane fetches per row (rows of up to 64*WPL words); waves per workgroup
+// four bytes of a word as two words of bf16 pairs; mode 0: unsigned bytes, 1: signed bytes, 2: signed where sg
+__device__ __forceinline__ uint2 bytes_to_bf16(unsigned w, int mode, bool sg) {
+  float f[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float fu = (float)((w >> (8 * i)) & 0xffu);
+    const float fs = (float)(int)(int8_t)(w >> (8 * i));
+    f[i] = mode == 0 ? fu : mode == 1 ? fs : (sg ? fs : fu);
+  }
+  return make_uint2(pack_hi16(__float_as_uint(f[0]), __float_as_uint(f[1])), pack_hi16(__float_as_uint(f[2]), __float_as_uint(f[3])));
+}
+
+template <int WPL, int NWAVE, bool BF>   // words a lane fetches per row (rows of up to 64*WPL words); waves per workgroup
 __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void conv_u8_kernel(
     const uint8_t* __restrict__ obs, const float* __restrict__ Wc, const float* __restrict__ bias, long M, int Rp, int T1,
     int H3, int plane_stride, long obs_bytes, float* __restrict__ x1) {
@@ -860,18 +880,32 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void conv_u8_kernel(
   const int KP = (T1 + 1) & ~1;                                  // K padded to a whole MFMA step
   const int nword = (T1 + 6) >> 2;                               // words that cover any alignment of T1 bytes
   unsigned char* Ab = cv_lds + (size_t)wave * CV_TILE * astr;    // this wave's rows: [CV_TILE][astr]
-  float* Wl = reinterpret_cast<float*>(cv_lds + (((size_t)NWAVE * CV_TILE * astr + 15) & ~(size_t)15));   // [KP][CV_WSTRIDE]
-  float* bl = Wl + (size_t)KP * CV_WSTRIDE;                      // [64]
-  // filters, transposed to [k][c]: a wave takes 64/NWAVE filters, lanes along k, all its loads in flight
-  constexpr int FPW = 64 / NWAVE;
-  for (int kb = 0; kb < KP; kb += 64) {
-    const int k = kb + lane;
-    float v[FPW];
+  unsigned char* bank = cv_lds + (((size_t)NWAVE * CV_TILE * astr + 15) & ~(size_t)15);
+  float* Wl = reinterpret_cast<float*>(bank);                    // !BF: [KP][CV_WSTRIDE] floats
+  const int KP16 = CV_KP16(T1), brow = CV_BROW(T1);              // BF: [3][64][brow] bytes
+  float* bl = BF ? reinterpret_cast<float*>(bank + (size_t)3 * 64 * brow) : Wl + (size_t)KP * CV_WSTRIDE;   // [64]
+  if (BF) {
+    for (int i = tid; i < 64 * KP16; i += 64 * NWAVE) {
+      const int c = i / KP16, k = i - c * KP16;
+      unsigned h, m, l;
+      split3(k < T1 ? Wc[(long)c * T1 + k] : 0.f, h, m, l);
+      unsigned short* d = reinterpret_cast<unsigned short*>(bank + (size_t)c * brow) + k;
+      d[0] = (unsigned short)(h >> 16);
+      d[(size_t)64 * brow / 2] = (unsigned short)(m >> 16);
+      d[(size_t)2 * 64 * brow / 2] = (unsigned short)(l >> 16);
+    }
+  } else {
+    // filters, transposed to [k][c]: a wave takes 64/NWAVE filters, lanes along k, all its loads in flight
+    constexpr int FPW = 64 / NWAVE;
+    for (int kb = 0; kb < KP; kb += 64) {
+      const int k = kb + lane;
+      float v[FPW];
 #pragma unroll
-    for (int ci = 0; ci < FPW; ci++) v[ci] = k < T1 ? Wc[(long)(wave * FPW + ci) * T1 + k] : 0.f;
-    if (k < KP) {
+      for (int ci = 0; ci < FPW; ci++) v[ci] = k < T1 ? Wc[(long)(wave * FPW + ci) * T1 + k] : 0.f;
+      if (k < KP) {
 #pragma unroll
-      for (int ci = 0; ci < FPW; ci++) Wl[k * CV_WSTRIDE + wave * FPW + ci] = v[ci];
+        for (int ci = 0; ci < FPW; ci++) Wl[k * CV_WSTRIDE + wave * FPW + ci] = v[ci];
+      }
     }
   }
   if (tid < 64) bl[tid] = bias[tid];
@@ -976,6 +1010,46 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void conv_u8_kernel(
       for (int j = 0; j < 2; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    if (BF) {
+      // per row tile: the lane's row, the byte offset of the row inside its first word, and whether all / none /
+      // some of the tile's rows are signed (wave-uniform)
+      const unsigned char* rp[2] = {Ab + c32 * astr + 8 * kh, Ab + (c32 + 32) * astr + 8 * kh};
+      const unsigned sh[2] = {(unsigned)os0 & 3u, (unsigned)os1 & 3u};
+      const bool sg[2] = {(os0 & 4) != 0, (os1 & 4) != 0};
+      int mode[2];
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const unsigned long long bs = __ballot(sg[j]);
+        mode[j] = bs == 0ull ? 0 : bs == ~0ull ? 1 : 2;
+      }
+      const unsigned char* ap = bank + (size_t)c32 * brow + 16 * kh;
+      for (int st = 0; st < KP16; st += 16) {
+        bf16x8 fa[2][3], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int t = 0; t < 3; t++)
+            fa[i][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + ((size_t)t * 64 + 32 * i) * brow + 2 * st));
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const unsigned* wp3 = reinterpret_cast<const unsigned*>(rp[j] + st);
+          const unsigned w0 = wp3[0], w1 = wp3[1], w2 = wp3[2];
+          const unsigned lo = __builtin_amdgcn_alignbyte(w1, w0, sh[j]), hi = __builtin_amdgcn_alignbyte(w2, w1, sh[j]);
+          const uint2 p = bytes_to_bf16(lo, mode[j], sg[j]), q = bytes_to_bf16(hi, mode[j], sg[j]);
+          fb[j] = __builtin_bit_cast(bf16x8, make_uint4(p.x, p.y, q.x, q.y));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) {
+            f32x16 c = acc[i][j];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j], c, 0, 0, 0);
+            acc[i][j] = c;
+          }
+      }
+    } else {
     auto kstep = [&](int kk) {
       const unsigned u0 = b0p[kk], u1 = b1p[kk];
       const float f0 = wp[kk * CV_WSTRIDE], f1 = wp[kk * CV_WSTRIDE + 32];
@@ -992,6 +1066,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void conv_u8_kernel(
       for (int u = 0; u < 4; u++) kstep(kk + 2 * u);
     }
     for (; kk < KP; kk += 2) kstep(kk);
+    }
     cv_wave_sync();                        // every lane has read its rows before the next tile overwrites them
     const unsigned o_rows = cur_rows;
     const unsigned d_lane = cur_drel;
@@ -1019,16 +1094,18 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void conv_u8_kernel(
   }
 }
 
-static size_t conv_u8_lds(int T1, int nwave) {
-  return (((size_t)nwave * CV_TILE * CV_ASTRIDE(T1) + 15) & ~(size_t)15) + ((size_t)((T1 + 1) & ~1) * CV_WSTRIDE + 64) * 4;
+static size_t conv_u8_lds(int T1, int nwave, bool bf) {
+  const size_t rows = ((size_t)nwave * CV_TILE * CV_ASTRIDE(T1) + 15) & ~(size_t)15;
+  // BF: 16 spare bytes behind the bias: the last row's third word may lie behind the rows of the last wave
+  return bf ? rows + (size_t)3 * 64 * CV_BROW(T1) + 64 * 4 + 16 : rows + ((size_t)((T1 + 1) & ~1) * CV_WSTRIDE + 64) * 4;
 }
 
-template <int WPL, int NWAVE>
+template <int WPL, int NWAVE, bool BF>
 static int launch_conv_u8(const uint8_t* obs_u8, const float* Wc, const float* bias, long M, int Rp, int T1, int H3,
                           int plane_stride, long obs_bytes, float* x1, hipStream_t stream) {
-  const size_t lds = conv_u8_lds(T1, NWAVE);
+  const size_t lds = conv_u8_lds(T1, NWAVE, BF);
   if (lds > 160 * 1024 - 512) return FLM_E_ARG;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8_kernel<WPL, NWAVE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8_kernel<WPL, NWAVE, BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds) != hipSuccess)
     return FLM_E_LAUNCH;
   // persistent workgroups: one per CU (256 CUs)
@@ -1036,7 +1113,7 @@ static int launch_conv_u8(const uint8_t* obs_u8, const float* Wc, const float* b
   long wgs = (tiles + NWAVE - 1) / NWAVE;
   if (wgs > 256) wgs = 256;
   if (wgs < 1) wgs = 1;
-  hipLaunchKernelGGL((conv_u8_kernel<WPL, NWAVE>), dim3((unsigned)wgs), dim3(64 * NWAVE), lds, stream, obs_u8, Wc, bias, M,
+  hipLaunchKernelGGL((conv_u8_kernel<WPL, NWAVE, BF>), dim3((unsigned)wgs), dim3(64 * NWAVE), lds, stream, obs_u8, Wc, bias, M,
                      Rp, T1, H3, plane_stride, obs_bytes, x1);
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
@@ -1096,12 +1173,19 @@ static int dqn_forward_impl(const float* params, const float* x, const uint8_t* 
     const int nword = (T1 + 6) >> 2;
     const float* cw = params + L.conv_w;
     const float* cb = params + L.conv_b;
-    if (nword <= 64 && flm::conv_u8_lds(T1, 8) <= 160 * 1024 - 512)        // two waves per SIMD share one filter bank
-      rc = flm::launch_conv_u8<1, 8>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
+    const size_t cap = 160 * 1024 - 512;
+    // on the bf16 matrix cores while the split filter bank fits the LDS beside the rows of 8 or 4 waves; longer
+    // horizons on fp32 instructions
+    if (nword <= 64 && flm::conv_u8_lds(T1, 8, true) <= cap)
+      rc = flm::launch_conv_u8<1, 8, true>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
+    else if (nword <= 64 && flm::conv_u8_lds(T1, 4, true) <= cap)
+      rc = flm::launch_conv_u8<1, 4, true>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
+    else if (nword <= 128 && flm::conv_u8_lds(T1, 4, true) <= cap)
+      rc = flm::launch_conv_u8<2, 4, true>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
     else if (nword <= 64)
-      rc = flm::launch_conv_u8<1, 4>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
+      rc = flm::launch_conv_u8<1, 4, false>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
     else if (nword <= 128)
-      rc = flm::launch_conv_u8<2, 4>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
+      rc = flm::launch_conv_u8<2, 4, false>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
     else
       rc = FLM_E_ARG;
     if (rc) return rc;
