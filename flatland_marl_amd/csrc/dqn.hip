@@ -348,9 +348,16 @@ template <bool A_KC, bool B_KC, int EPI>
 static int launch_gemm(const GemmArgs& g, int nz, hipStream_t stream) {
   dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, nz);
   {
-    static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<A_KC, B_KC, EPI>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES) == hipSuccess;
-    if (!lds_ok) return FLM_E_LAUNCH;
+    // the kernel's LDS size is raised once per device (the attribute belongs to the device's copy of the kernel)
+    static bool lds_set[64];
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return FLM_E_LAUNCH;
+    if (!lds_set[dev]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<A_KC, B_KC, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES) != hipSuccess)
+        return FLM_E_LAUNCH;
+      lds_set[dev] = true;
+    }
     hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, EPI>), grid, dim3(512), X3_LDS_BYTES, stream, g);
   }
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
