@@ -12,6 +12,7 @@
 //   conv1.weight[64,T1] conv1.bias[64] fc1_adv.weight[512,K1] fc1_adv.bias[512] fc1_val.weight[512,K1]
 //   fc1_val.bias[512] fc2_adv.weight[NA,512] fc2_adv.bias[NA] fc2_val.weight[1,512] fc2_val.bias[1],  K1 = 64*H3.
 #include <cstdlib>
+#include <algorithm>
 #include <type_traits>
 
 #include "flm_common.h"
@@ -821,16 +822,44 @@ __global__ void soft_update_kernel(float* __restrict__ target, const float* __re
 }
 
 // uint8 observation planes (own plane is int8) -> fp32 rows [n, H3=3*Rp, T1]
-__global__ void obs_to_f32_kernel(const uint8_t* __restrict__ obs, int n, int Rp, int T1, int plane_stride, float* __restrict__ out) {
-  const long total = (long)n * 3 * Rp * T1;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long per = (long)Rp * T1;
-    const long s = i / (3 * per), rem = i - s * 3 * per;
-    const int pl = (int)(rem / per);
-    const long o = rem - pl * per;
-    const uint8_t u = obs[(s * 3 + pl) * plane_stride + o];
-    out[i] = pl == 0 ? (float)(int8_t)u : (float)u;
+// Workgroup = (piece of a plane, plane of a sample): no division per element; a thread converts four consecutive
+// bytes and stores 16 bytes where the output is aligned for it.
+__global__ __launch_bounds__(256) void obs_to_f32_kernel(const uint8_t* __restrict__ obs, int n, int Rp, int T1, int plane_stride,
+                                                         float* __restrict__ out) {
+  const long per = (long)Rp * T1;
+  const int sp = blockIdx.y;                              // sample * 3 + plane
+  const int pl = sp % 3;
+  const uint8_t* src = obs + (long)sp * plane_stride;
+  float* dst = out + (long)sp * per;
+  const bool al = (reinterpret_cast<size_t>(dst) & 15) == 0, al_src = (reinterpret_cast<size_t>(src) & 3) == 0;
+  for (long o = ((long)blockIdx.x * 256 + threadIdx.x) * 4; o < per; o += (long)gridDim.x * 1024) {
+    float f[4];
+    if (al_src && o + 3 < per) {
+      const unsigned w = *reinterpret_cast<const unsigned*>(src + o);
+#pragma unroll
+      for (int i = 0; i < 4; i++) f[i] = pl == 0 ? (float)(int8_t)(w >> (8 * i)) : (float)((w >> (8 * i)) & 0xffu);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const uint8_t u = o + i < per ? src[o + i] : 0;
+        f[i] = pl == 0 ? (float)(int8_t)u : (float)u;
+      }
+    }
+    if (al && o + 3 < per) {
+      *reinterpret_cast<float4*>(dst + o) = make_float4(f[0], f[1], f[2], f[3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (o + i < per) dst[o + i] = f[i];
+    }
   }
+}
+
+// pieces of 4 KiB a plane is cut into (grid x of obs_to_f32_kernel), at most 8
+static unsigned obs_to_f32_pieces(int Rp, int T1) {
+  const long per = (long)Rp * T1;
+  long p = (per + 4095) / 4096;
+  return (unsigned)(p < 1 ? 1 : p > 8 ? 8 : p);
 }
 
 // ---- convolution straight from uint8 observations ----------------------------------------------------
@@ -1258,8 +1287,11 @@ extern "C" int flm_dqn_forward_u8(const float* params, const uint8_t* obs, int n
 
 extern "C" int flm_obs_to_f32(const uint8_t* obs, int n, int Rp, int T1, int plane_stride, float* out, void* stream) {
   if (!obs || !out || n <= 0 || Rp <= 0 || T1 <= 0 || (long)plane_stride < (long)Rp * T1) return FLM_E_ARG;
-  hipLaunchKernelGGL(flm::obs_to_f32_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, obs, n, Rp, T1, plane_stride,
-                     out);
+  if ((long)n * 3 > 65535 * 64L) return FLM_E_ARG;
+  for (long s0 = 0; s0 < (long)n * 3; s0 += 65535)      // the grid's y extent is 65,535
+    hipLaunchKernelGGL(flm::obs_to_f32_kernel, dim3(flm::obs_to_f32_pieces(Rp, T1), (unsigned)std::min(65535L, (long)n * 3 - s0)),
+                       dim3(256), 0, (hipStream_t)stream, obs + s0 * plane_stride, n, Rp, T1, plane_stride,
+                       out + s0 * (long)Rp * T1);
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
 }
@@ -1299,8 +1331,9 @@ static int learn_grads_impl(const float* local, const float* target, const float
   float* dadv = dq + (long)NA * B; float* dval = dadv + (long)NA * B; float* sq = dval + B;
   int rc;
   if (s_u8) {
-    hipLaunchKernelGGL(flm::obs_to_f32_kernel, dim3(2048), dim3(256), 0, stream, s_u8, B, H3 / 3, T1, plane_stride,
-                       const_cast<float*>(s));
+    if ((long)B * 3 > 65535) return FLM_E_ARG;
+    hipLaunchKernelGGL(flm::obs_to_f32_kernel, dim3(flm::obs_to_f32_pieces(H3 / 3, T1), B * 3), dim3(256), 0, stream, s_u8, B,
+                       H3 / 3, T1, plane_stride, const_cast<float*>(s));
     if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   }
   if ((rc = dqn_forward_impl(local, s_u8 ? nullptr : s, s_u8, plane_stride, B, H3, T1, NA, x1, hid, part, q, stream))) return rc;
