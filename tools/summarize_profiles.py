@@ -45,8 +45,8 @@ json.dump({"workload": "tools/dqn_bench.py (B=512, max_rails=100, depth 150), ro
                        "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE", "mfma_util": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); GRBM_GUI_ACTIVE is summed over the "
                         "8 XCDs (it reads 8x duration x clock); the busy counter advances 64 cycles per v_mfma_f32_32x32x2_f32 "
                         "and 32 per v_mfma_f32_32x32x16_bf16, so this is the fraction of the time the matrix pipes are busy: "
-                        "of the fp32 matrix peak for conv_u8_kernel, and for gemm_x3_kernel (six bf16 instructions per "
-                        "16 k of a 32x32 tile) one sixth of the bf16 peak = 417 TFLOP/s of fp32-equivalent products",
+                        "for gemm_x3_kernel (six bf16 instructions per 16 k of a 32x32 tile) a busy fraction of 1 would be one sixth "
+                        "of the bf16 peak = 417 TFLOP/s of fp32-equivalent products; conv_u8_kernel needs three per 16 k",
            "kernels": dq}, open(os.path.join(OUT, "%s_dqn_mfma.json" % tag), "w"), indent=1)
 
 # HBM traffic of the bench step: 64-byte write requests counted apart from 32-byte ones, reads likewise
