@@ -79,7 +79,8 @@ struct GemmArgs {
 // a_lo*b_lo) is below 2^-21 of the product, 2^-23 on average: the rounding of an fp32 multiply-add.  Six bf16
 // instructions of 32 cycles cover the sixteen k of eight fp32 instructions of 64 cycles.  Infinities and NaNs
 // in the operands give NaN.
-// Workgroup tile 128x128, 4 waves as 2x2, each wave 2x2 tiles of 32x32.  Memory is read 32 k at a time into
+// Workgroup tile 128x128, 8 waves as 2x4, each wave 2x1 tiles of 32x32 (at most 128 registers: four waves per
+// SIMD with two workgroups on a CU).  Memory is read 32 k at a time into
 // registers (two fetches in flight), LDS is filled 16 k at a time: a stage holds [split][row][16 k] for both
 // operands, a lane's operand of one instruction is one 16-byte read, rows are 48 bytes apart (an odd number of
 // 16-byte slots: the reads of a 16-lane group fall into 16 different slots).  There are two stages: while the
