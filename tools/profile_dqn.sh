@@ -1,11 +1,13 @@
 #!/bin/bash
-# Kernel statistics of tools/dqn_bench.py under rocprofv3 (argument: output tag); prints the top kernels.
+# Kernel statistics of tools/dqn_bench.py under rocprofv3 (arguments: output tag, then dqn_bench.py's own); prints the
+# top kernels.
 set -e
 TAG=${1:-dqn}
+shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_$TAG
 mkdir -p $O
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $O -o dqn --output-format csv -- python3 tools/dqn_bench.py > $O/dqn.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $O -o dqn --output-format csv -- python3 tools/dqn_bench.py "$@" > $O/dqn.log 2>&1
 python3 - "$O" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/dqn_kernel_stats.csv", recursive=True)[0]

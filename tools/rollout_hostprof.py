@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--train", action="store_true")
     args = ap.parse_args()
+    torch.manual_seed(0)      # the same weights, hence the same decisions and request counts, on every run
     data, E, A, depth, _ = bench.workload_batch("cfg2g", args.envs)
     b = fm.ObservationBatch(data["grid"], data["start"], data["direction"], data["target"], data["speed"], depth, max_rails=70)
     ro = RolloutBatch(b, data["speed"], data["direction"], max_alt_depth=203,
