@@ -277,6 +277,25 @@ def test_forward_wide_dynamic_range_vs_float64(B, H3, T1):
     assert err <= 4 * err32 + 1e-6 * scale, (err, err32, scale)
 
 
+@pytest.mark.parametrize("n,Rp,T1,ps,off", [(7, 5, 13, 80, 0), (3, 70, 151, 10752, 0), (22000, 2, 5, 16, 0), (9, 4, 9, 48, 1)])
+def test_byte_planes_to_float_rows(n, Rp, T1, ps, off):
+    """flm_obs_to_f32: plane 0 is read as int8, the heat planes as uint8; rows of Rp*T1 values are packed without the
+    plane padding.  Covers planes shorter than a workgroup's piece, more than 65,535 planes (two launches), and a
+    source that is not word aligned."""
+    from flatland_marl_amd._lib import call, ptr
+    g = torch.Generator().manual_seed(n + Rp)
+    raw = torch.randint(0, 256, (n * 3 * ps + 4,), generator=g, dtype=torch.uint8).cuda()
+    obs = raw[off:off + n * 3 * ps]
+    out = torch.full((n * 3 * Rp * T1 + 8,), -7.0, device="cuda")
+    call("flm_obs_to_f32", ptr(obs), n, Rp, T1, ps, ptr(out), torch.cuda.current_stream().cuda_stream)
+    planes = obs.view(n, 3, ps)[:, :, :Rp * T1].cpu().numpy()
+    want = planes.astype(np.float32)
+    want[:, 0] = planes[:, 0].view(np.int8).astype(np.float32)
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:n * 3 * Rp * T1].reshape(n, 3, Rp * T1), want)
+    assert np.all(got[n * 3 * Rp * T1:] == -7.0)          # nothing behind the last row is written
+
+
 @pytest.mark.parametrize("B,Rp,T1,pad", [(5, 10, 21, 0), (300, 7, 151, 3), (33, 4, 301, 1), (700, 100, 151, 0)])
 def test_forward_from_uint8_observations_vs_torch(B, Rp, T1, pad):
     """The byte-input forward (convolution reads int8 / uint8 planes) against plain PyTorch fp32 on the same values;
