@@ -1040,13 +1040,16 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void conv_u8_kernel(
     const unsigned wd0 = os0 & 4 ? 8u : 9u, wd1 = os1 & 4 ? 8u : 9u;
     const unsigned char* b0p = Ab + c32 * astr + kh + (os0 & 3);
     const unsigned char* b1p = Ab + (c32 + 32) * astr + kh + (os1 & 3);
+    // the accumulators start from the bias of their filter (32 look-ups per tile instead of one per stored value)
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-      for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; r++) {
+        const float bv = bl[32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh];
+        acc[i][0][r] = bv;
+        acc[i][1][r] = bv;
+      }
     if (BF) {
       // per row tile: the lane's row, the byte offset of the row inside its first word, and whether all / none /
       // some of the tile's rows are signed (wave-uniform)
@@ -1124,7 +1127,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void conv_u8_kernel(
 #pragma unroll
           for (int r = 0; r < 16; r++) {
             const int c = 32 * i + (r & 3) + 8 * (r >> 2);
-            dst0[d + (unsigned)c * uH3] = fmaxf(acc[i][j][r] + bl[c + 4 * kh], 0.f);
+            dst0[d + (unsigned)c * uH3] = fmaxf(acc[i][j][r], 0.f);
           }
       }
     }
