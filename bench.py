@@ -159,6 +159,50 @@ def guarded_rollout_sample(out, rank, timeout_s, **kw):
     return res
 
 
+def dqn_sample(device, B=512, max_rails=100, depth=150):
+    """The network's kernels on their own (N = 1 only): forward and one learn step at the script's batch size straight
+    from uint8 observations, and act at batch 1; event-timed medians.  flop counts one multiply-add as two."""
+    import types
+    from flatland_marl_amd.agent import DQNAgent
+    H3, T1 = 3 * max_rails, depth + 1
+    a = types.SimpleNamespace(prediction_depth=depth, lr=5e-5, buffer_size=10, batch_size=B, update_every=10, gamma=0.99,
+                              tau=1e-3)
+    torch.manual_seed(0)
+    agent = DQNAgent(a, action_space=2, bitmap_height=H3)
+    g = torch.Generator().manual_seed(0)
+    ps = (max_rails * T1 + 255) // 256 * 256
+    obs = torch.randint(0, 3, (B, 3, ps), generator=g, dtype=torch.uint8).to(device)
+    obs_n = torch.randint(0, 3, (B, 3, ps), generator=g, dtype=torch.uint8).to(device)
+    act = torch.randint(0, 2, (B,), generator=g).to(device)
+    r = torch.randn(B, generator=g).to(device)
+    d = (torch.rand(B, generator=g) < 0.1).float().to(device)
+    one = torch.randint(-1, 3, (1, 1, H3, T1), generator=g).float().to(device)
+
+    def timed(fn, reps=10, warm=2):
+        for _ in range(warm):
+            fn()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for x, y in ev:
+            x.record()
+            fn()
+            y.record()
+        torch.cuda.synchronize()
+        return float(np.median([x.elapsed_time(y) for x, y in ev]))
+
+    fwd_flop = (2.0 * H3 * T1 * 64 + 4.0 * 64 * H3 * 512) * B
+    t_f = timed(lambda: agent.qnetwork_local.forward_obs(obs, ps))
+    t_l = timed(lambda: agent.learn_obs((obs, act, r, obs_n, d), 0.99, ps))
+    t_a = timed(lambda: agent.qnetwork_local(one), reps=30)
+    return {"workload": "batch %d, max_rails %d, depth %d, uint8 observations" % (B, max_rails, depth),
+            "forward_ms": t_f, "forward_TFLOPs": fwd_flop / t_f / 1e9,
+            "learn_step_ms": t_l, "learn_step_TFLOPs": 5 * fwd_flop / t_l / 1e9,
+            "act_batch1_ms": t_a,
+            "note": "fp32 values; the matrix products run on the bf16 matrix cores with every fp32 operand split into "
+                    "three bf16 terms (six partial products: one sixth of the bf16 peak = 417 TFLOP/s bounds them; "
+                    "fp32 matrix instructions peak at 157); a learn step is three forward passes, the backward pass "
+                    "(about two more), Adam and the target's soft update"}
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -229,6 +273,7 @@ def main():
     ap.add_argument("--no-store-paths", action="store_true", help="fused only: do not write the path elements to HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rollout", action="store_true", help="skip the env-steps/s sample of the batched rollout")
+    ap.add_argument("--no-dqn", action="store_true", help="skip the timing of the network's kernels")
     ap.add_argument("--rollout-workload", default="cfg2g", choices=["cfg2", "cfg2g"])
     ap.add_argument("--rollout-max-rails", type=int, default=70)
     ap.add_argument("--rollout-envs", type=int, default=0, help="environments per GPU of the env-steps/s sample")
@@ -438,6 +483,11 @@ def main():
                                      max_rails=args.rollout_max_rails, world=world, envs=args.rollout_envs,
                                      steps=args.rollout_steps)
         out["env_steps"] = res
+    if rank == 0 and world == 1 and not args.no_dqn:
+        try:
+            out["dqn"] = dqn_sample(device)
+        except Exception as ex:                       # the observation figures stand without it
+            out["dqn"] = {"error": repr(ex)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
