@@ -79,19 +79,47 @@ def cpu_baseline(data, depth, Rp, budget_s=12.0, max_envs=64):
         n_env += 1
         n_obs += A
     dt = time.perf_counter() - t0
-    return dict(value=n_obs / dt, unit="agent-observations/s", cores=1, kind="port",
-                sample="%d environments (%d agent-observations) of the same batch in %.1f s, single thread, "
-                       "C restatement of the reference algorithm (oracle/flmarl_oracle.c)" % (n_env, n_obs, dt))
+    out = dict(value=n_obs / dt, unit="agent-observations/s", cores=1, kind="port",
+               sample="%d environments (%d agent-observations) of the same batch in %.1f s, single thread, "
+                      "C restatement of the reference algorithm (oracle/flmarl_oracle.c)" % (n_env, n_obs, dt))
+    ref = reference_python_constant()
+    if ref is not None:
+        out["reference_python"] = ref
+    return out
 
 
-def rollout_sample(device, steps=40, workload="cfg2g", max_rails=70, rank=0, world=1, envs=0):
+def reference_python_constant():
+    """The reference's own Python (src/rail_observations.py get_many + src/preprocessing.py get_obs for every
+    agent, unmodified modules, one thread) timed once in the build container on the bundled 100x100 map this
+    workload is drawn from; the reference cannot run beside the GPU, so the figure is a stated constant read
+    from a committed file, not something this run measured."""
+    path = os.path.join(ROOT, "tests", "golden", "ref_timing.json")
+    if not os.path.exists(path):
+        return None
+    t = json.load(open(path))
+    k = t.get("Test_8_Level_0_d150")
+    if not k:
+        return None
+    secs = k["graph_s"] + k["dist_shim_s"] + k["get_many_s"] + k["get_obs_all_s"]
+    return dict(value=k["agents"] / secs, unit="agent-observations/s", cores=1,
+                host="build container, %d-core Xeon, Python 3.10, numpy 2.2" % t.get("_host", {}).get("cpus", 8),
+                note="constant from tests/golden/ref_timing.json: Test_8/Level_0, %d agents, %d rails, depth 150: "
+                     "graph %.2f s + distance map %.2f s + get_many %.2f s + get_obs for all agents %.2f s "
+                     "(src/preprocessing.py:24-30 is the last term)"
+                     % (k["agents"], k["rails"], k["graph_s"], k["dist_shim_s"], k["get_many_s"], k["get_obs_all_s"]))
+
+
+def rollout_sample(device, steps=40, workload="cfg2g", max_rails=70, rank=0, world=1, envs=0, ref_cadence_steps=10):
     """Environment steps per second of the batched rollout (src/main.py:142-299 for every environment at once)
     on the 1024 x 10 workload (generated 25x25 grids, max_rails = 70; the script itself pads to 100 rails,
     src/main.py:91, which --rollout-max-rails 100 reproduces): the network
     consulted by every departing agent and every agent in front of a switch, first without, then with
-    learning (one learn step per 10 stored transitions, at most 4 per rollout step).  With several ranks every
-    rank steps environments of its own and the learn steps all-reduce the gradient; value = all ranks'
-    environment steps / the slowest rank's time."""
+    learning in two forms.  `act_and_learn_ref_cadence` is the reference's rule: one learn step per `update_every`
+    = 10 stored transitions (src/agent.py:57-67, src/main.py:386-391), however many that is per rollout step; it is
+    what a "full training rollout" means.  `act_and_learn` caps the learn steps of one rollout step at 4: a
+    different, cheaper algorithm, kept as the figure of earlier runs.  Both say so in `learn_cadence`.  With
+    several ranks every rank steps environments of its own and the learn steps all-reduce the gradient; value =
+    all ranks' environment steps / the slowest rank's time."""
     import types
     import flatland_marl_amd as fm
     from flatland_marl_amd.agent import DQNAgent
@@ -109,13 +137,16 @@ def rollout_sample(device, steps=40, workload="cfg2g", max_rails=70, rank=0, wor
     torch.manual_seed(0)                                     # identical replicas on every rank
     agent = DQNAgent(a, action_space=2, bitmap_height=3 * b.Rp)
     tr = BatchedTrainer(ro, agent, start_eps=0.1, max_learns_per_step=4, seed=rank)
+    ref_steps = max(2, min(steps, ref_cadence_steps))
     out = {"unit": "env-steps/s", "config": {"workload": workload + ": " + desc, "envs_per_gpu": E, "n_gpus": world,
                                              "agents": A, "rails_padded": int(b.Rp),
                                              "depth": depth, "steps_timed": steps, "eps": 0.1,
                                              "speeds": "1, 1/2, 1/3, 1/4", "malfunction": malf}}
-    for key, train in (("act_only", False), ("act_and_learn", True)):
+    for key, train, cap, steps in (("act_only", False, 4, steps), ("act_and_learn", True, 4, steps),
+                                   ("act_and_learn_ref_cadence", True, None, ref_steps)):
+        tr.max_learns_per_step = cap
         ro.reset()
-        for _ in range(6):                                   # first calls size the buffers
+        for _ in range(6 if cap is not None else 3):         # first calls size the buffers
             tr.step(train=train)
         n0, l0 = tr.n_transitions, tr.n_learn
         torch.cuda.synchronize()
@@ -130,7 +161,13 @@ def rollout_sample(device, steps=40, workload="cfg2g", max_rails=70, rank=0, wor
         out[key] = {"value": E * world / dt, "ms_per_step": dt * 1e3,
                     "transitions_per_step": (tr.n_transitions - n0) / steps,
                     "learn_steps_per_step": (tr.n_learn - l0) / steps,
-                    "agents_flagged": flagged, "agents_over_capacity": overflowed}
+                    "agents_flagged": flagged, "agents_over_capacity": overflowed, "steps_timed": steps}
+        if train:
+            out[key]["learn_cadence"] = {
+                "update_every": a.update_every, "batch_size": a.batch_size, "cap_per_rollout_step": cap,
+                "is_reference_cadence": cap is None,
+                "note": "one learn step per update_every stored transitions (src/agent.py:57-67)" if cap is None else
+                        "NOT the reference's cadence: learn steps per rollout step capped at %d" % cap}
         if overflowed:
             raise OverflowError("%d agents exceeded the rollout's alternative / path capacities" % overflowed)
     return out
@@ -479,7 +516,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data, depth, int(Rp))
     if not args.no_rollout:
-        res = guarded_rollout_sample(out, rank, 240, device=device, workload=args.rollout_workload,
+        res = guarded_rollout_sample(out, rank, 300, device=device, workload=args.rollout_workload,
                                      max_rails=args.rollout_max_rails, world=world, envs=args.rollout_envs,
                                      steps=args.rollout_steps)
         out["env_steps"] = res

@@ -1,6 +1,8 @@
 """flm_bitmaps_static (the entry point that allocates nothing: its column workspace is a fixed array inside the
 library) against flm_bitmaps, through the C ABI, on two calls in a row, the second with a smaller input.
 Bit-exact.  Needs an MI355X."""
+import gc
+
 import numpy as np
 import pytest
 
@@ -23,12 +25,23 @@ def _both(b, n_paths, agent_flat, shift):
     call("flm_bitmaps", *common, ptr(ws), ptr(want), ptr(want_err), s)
     got = torch.full((n_paths, b.plane_stride), 9, dtype=torch.int8, device=dev)
     got_err = torch.full((n_paths,), -9, dtype=torch.int32, device=dev)
+    # What can see an allocation made inside the library is the driver's own count of free device memory
+    # (hipMemGetInfo); torch's counter only sees torch's allocator and moves whenever Python's collector frees
+    # tensors of earlier tests, so the collector is run first and held off around the call.
+    gc.collect()
     torch.cuda.synchronize()
-    before = torch.cuda.memory_allocated(dev)
-    call("flm_bitmaps_static", *common, ptr(got), ptr(got_err), s)
-    torch.cuda.synchronize()
-    assert torch.cuda.memory_allocated(dev) == before
-    return want.cpu().numpy(), want_err.cpu().numpy(), got.cpu().numpy(), got_err.cpu().numpy()
+    gc.disable()
+    try:
+        free_before = torch.cuda.mem_get_info(dev)[0]
+        torch_before = torch.cuda.memory_allocated(dev)
+        call("flm_bitmaps_static", *common, ptr(got), ptr(got_err), s)
+        torch.cuda.synchronize()
+        free_after = torch.cuda.mem_get_info(dev)[0]
+        torch_after = torch.cuda.memory_allocated(dev)
+    finally:
+        gc.enable()
+    alloc = (free_before, free_after, torch_before, torch_after)
+    return want.cpu().numpy(), want_err.cpu().numpy(), got.cpu().numpy(), got_err.cpu().numpy(), alloc
 
 
 def test_static_workspace_entry_point_matches_flm_bitmaps():
@@ -41,7 +54,7 @@ def test_static_workspace_entry_point_matches_flm_bitmaps():
     b.compute_distances()
     b.shortest_paths()
     # first call: every agent's path
-    want, werr, got, gerr = _both(b, b.E * b.A, None, 1)
+    want, werr, got, gerr, alloc1 = _both(b, b.E * b.A, None, 1)
     assert np.array_equal(werr, gerr) and np.array_equal(want, got)
     assert np.abs(want).sum() > 0
     # second call, smaller: 7 agents' paths, not shifted (the workspace still holds the first call's columns)
@@ -51,7 +64,7 @@ def test_static_workspace_entry_point_matches_flm_bitmaps():
     small.build_graph()
     small.compute_distances()
     small.shortest_paths()
-    want2, werr2, got2, gerr2 = _both(small, 7, None, 0)
+    want2, werr2, got2, gerr2, alloc2 = _both(small, 7, None, 0)
     assert np.array_equal(werr2, gerr2) and np.array_equal(want2, got2)
     # the planes are the ones the checked path produces for those agents (shift 0 vs shift 1: one column apart)
     full = want.reshape(b.A, -1)[:, : b.Rp * b.T1].reshape(b.A, b.Rp, b.T1)
@@ -68,3 +81,7 @@ def test_static_workspace_entry_point_matches_flm_bitmaps():
                   b.H, b.W, b.capR, b.Rp, b.T1, b.plane_stride, b.Lcap, 1, b.path_cell.data_ptr(), b.path_len.data_ptr(),
                   b.stream.cuda_stream)
     assert rc == -3
+    # last, so that a quirk of a counter can never hide the comparisons above: neither call took device memory
+    for free_before, free_after, torch_before, torch_after in (alloc1, alloc2):
+        assert free_after >= free_before, (free_before, free_after)
+        assert torch_after <= torch_before, (torch_before, torch_after)
