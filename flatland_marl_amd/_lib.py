@@ -14,7 +14,7 @@ FLM_OK = 0
 AGENT_ERRORS = {2: IndexError, 3: KeyError, 4: AssertionError, 5: OverflowError}
 GRAPH_ERR_NODES, GRAPH_ERR_RAILS, GRAPH_ERR_CELLS, GRAPH_ERR_STATES = 1, 2, 4, 8
 MAX_NODES = 2048
-ABI_VERSION = 3
+ABI_VERSION = 4
 DQN_MAX_ACTIONS = 16                                       # FLM_DQN_MAX_ACTIONS of include/flmarl.h
 
 _p = C.c_void_p
@@ -59,6 +59,8 @@ _SIGNATURES = {
     "flm_obs_to_f32": [_p, _i, _i, _i, _i, _p, _p],
     "flm_dqn_forward_u8": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "flm_dqn_learn_grads": [_p, _p, _p, _p, _p, _p, _p, C.c_float, _i, _i, _i, _i, _i, _p, _p, _p, _p],
+    "flm_observations_req_columns_rows": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
+    "flm_replay_store": [_p, _i, _p, _i, _p, _p, C.c_long, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "flm_replay_sample": [_i, _i, _u32, _u32, _p, _p],
     "flm_replay_gather": [_p, _p, _p, _p, _p, _p, _i, C.c_long, _p, _p, _p, _p, _p, _p],
     "flm_dqn_adam": [_p, _p, _p, _p, C.c_long, C.c_double, C.c_double, C.c_double, C.c_double, _i, _p],

@@ -173,7 +173,10 @@ class ReplayBuffer:
     """The reference's fixed-size buffer of experience tuples with uniform sampling (src/agent.py:134-198), kept in
     device memory: add() uploads one transition (states as float32 [height*width]), sample() draws batch_size of
     them without replacement and returns the reference's five tensors (states and next states [B,1,height,width]
-    float, actions long, rewards and dones float) on the device."""
+    float, actions long, rewards and dones float) on the device, as fresh tensors the caller may keep (the
+    reference stacks new tensors per call, src/agent.py:163-172).  One visible difference: the sampled transitions
+    come back in ring order, not in random.sample's order; the loss and its gradients do not depend on the order
+    of a batch."""
 
     def __init__(self, action_space, buffer_size, batch_size, width, height):
         self.action_space = action_space
@@ -198,15 +201,17 @@ class ReplayBuffer:
         return x.to(device)
 
     def add(self, state, action, reward, next_state, done):
-        self.memory.add(self._row(state), torch.tensor([int(action)], device=device),
-                        torch.tensor([float(reward)], device=device), self._row(next_state),
-                        torch.tensor([1.0 if done else 0.0], device=device))
+        # the three scalars travel as one small upload
+        ard = torch.tensor([float(int(action)), float(reward), 1.0 if done else 0.0], dtype=torch.float64).to(device)
+        self.memory.add(self._row(state), ard[0:1].to(torch.int64), ard[1:2].to(torch.float32), self._row(next_state),
+                        ard[2:3].to(torch.float32))
 
     def sample(self):
+        # DeviceReplay.sample returns buffers of its own that the next call overwrites: hand out copies
         s, a, r, sn, d = self.memory.sample(self.batch_size)
         n = self.height * self.width
         shape = (self.batch_size, 1, self.height, self.width)
-        return s[:, :n].reshape(shape), a, r, sn[:, :n].reshape(shape), d
+        return s[:, :n].reshape(shape).clone(), a.clone(), r.clone(), sn[:, :n].reshape(shape).clone(), d.clone()
 
     def __len__(self):
         return 0 if self._memory is None else len(self._memory)

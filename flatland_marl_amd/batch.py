@@ -92,6 +92,7 @@ class ObservationBatch:
 
     def _launch_graph(self):
         E, H, W = self.E, self.H, self.W
+        self._chain_ready = False                            # a chain index built before this launch is stale
         s = self.stream.cuda_stream
         call("flm_graph_build", ptr(self.grid), E, H, W, self.capN, self.capR, self.capC, ptr(self.node_id),
              ptr(self.node_cell), ptr(self.edge_info), ptr(self.edge_cell_off), ptr(self.edge_cells),
@@ -147,7 +148,10 @@ class ObservationBatch:
     def check_graph(self):
         """Raise if any asynchronous build_graph since the last check overflowed or changed the rail counts."""
         counts = self.counts.cpu().numpy()
-        if int(np.bitwise_or.reduce(counts[:, 3])) != 0 or int(counts[:, 1].max()) > self.Rp:
+        flags = int(np.bitwise_or.reduce(counts[:, 3]))
+        if flags & _lib.GRAPH_ERR_STATES:
+            self.lds_anchor = self.lds_slots = None          # outgrown: sized again by the next chain_index()
+        if flags != 0 or int(counts[:, 1].max()) > self.Rp:
             raise _lib.FlmError("graph capacities exceeded in an asynchronous build")
 
     # ------------------------------------------------------------------ distances and paths
@@ -177,7 +181,9 @@ class ObservationBatch:
                  A, self.H, self.W, self.cap_cells, ptr(self.tslot), ptr(self.n_slots), ptr(self.slot_target),
                  ptr(self.dist), s)
             return self
-        self.chain_index()
+        if not getattr(self, "_chain_ready", False):         # reset_fused() may have built it for these grids already
+            self.chain_index()
+        self._chain_ready = False                            # one use: positions and targets may change before the next call
         if self.lds_anchor * 80 > 159 * 1024:                # the anchors' labels of 32 targets do not fit the LDS
             return self.compute_distances(method="bfs")
         call("flm_distance_chains", ptr(self.chain_root), ptr(self.chain_steps), ptr(self.chain_edges),
@@ -217,10 +223,12 @@ class ObservationBatch:
              ptr(self.chain_edges), ptr(self.n_anchor), ptr(self.counts), ptr(self.chain_succ), ptr(self.chain_choice),
              ptr(self.chain_walk), ptr(self.move_edge), ptr(self.move_succ), ptr(self.idx_cell), s)
         self._succ_valid = True
+        self._chain_ready = True                             # the chain index of the current grids and targets is in place
         if getattr(self, "lds_anchor", None) is None:
             # anchors = states with a choice of moves (fixed by the grid) + states on target cells (<= 4*A).
             # The LDS tables are sized for the count seen now plus a margin for later target assignments;
-            # an environment that outgrows it is flagged in counts (check_graph) and this size is recomputed.
+            # an environment that outgrows it is flagged in counts: check_graph() then forgets this size, and
+            # the next chain_index() takes it from the counts of that launch.
             n_now = int(self.n_anchor.max().item())
             self.lds_anchor = int(min(self.cap_anchor, n_now + min(4 * A, 64)))
             # distinct targets per environment, rounded up to the eight targets one decision word holds

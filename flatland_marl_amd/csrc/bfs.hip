@@ -185,15 +185,11 @@ extern "C" int flm_distance_bfs(const uint16_t* pred, const int32_t* cell_idx, c
   size_t lds = (pred_lds ? pred_bytes : 0) + per_wave * nw;
   dim3 grid((A + nw - 1) / nw, E);
   if (pred_lds) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flm::distance_bfs_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return FLM_E_LAUNCH;
+    FLM_RAISE_LDS_ONCE(flm::distance_bfs_kernel<true>);
     hipLaunchKernelGGL(flm::distance_bfs_kernel<true>, grid, dim3(nw * 64), lds, stream, pred, cell_idx, n_cells,
                        slot_target, n_slots, A, H * W, capCells, dist);
   } else {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flm::distance_bfs_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return FLM_E_LAUNCH;
+    FLM_RAISE_LDS_ONCE(flm::distance_bfs_kernel<false>);
     hipLaunchKernelGGL(flm::distance_bfs_kernel<false>, grid, dim3(nw * 64), lds, stream, pred, cell_idx, n_cells,
                        slot_target, n_slots, A, H * W, capCells, dist);
   }

@@ -448,9 +448,13 @@ __global__ __launch_bounds__(256) void observations_req_columns_kernel(const int
                                                                        const int16_t* __restrict__ own_cols,
                                                                        const int32_t* __restrict__ own_row, int A, int T1,
                                                                        int plane_stride, int tile_bytes,
+                                                                       const int32_t* __restrict__ out_row,
                                                                        uint8_t* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned req_tile[];   // [3][tile_bytes/4]: own plane, positive heat, negative heat (packed bytes)
   const int g = blockIdx.y, tid = threadIdx.x;
+  // out_row (optional): the row of `out` that request g writes (negative: the request is skipped), else row g
+  const int dst_row = out_row ? out_row[g] : g;
+  if (dst_row < 0) return;
   const int ga = req_agent[g];
   const int e = ga / A, a = ga - e * A;
   const int p0 = blockIdx.x * tile_bytes;
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(256) void observations_req_columns_kernel(const int
   }
   __syncthreads();
   const int n16 = min(tile_bytes, plane_stride - p0) / 16;
-  uint8_t* o = out + (size_t)g * 3 * plane_stride + p0;
+  uint8_t* o = out + (size_t)dst_row * 3 * plane_stride + p0;
   for (int i = tid; i < n16; i += 256) {
     reinterpret_cast<uint4*>(o)[i] = reinterpret_cast<const uint4*>(req_tile)[i];
     reinterpret_cast<uint4*>(o + plane_stride)[i] = reinterpret_cast<const uint4*>(req_tile + tw)[i];
@@ -668,9 +672,8 @@ static int launch_obs_cols(const int16_t* cols, int E, int A, int T1, int plane_
                            hipStream_t stream) {
   dim3 grid((plane_stride + 1024 * CH - 1) / (1024 * CH), E);
   size_t lds = (size_t)CH * (2048 + 1024 * (size_t)nw);
-  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(flm::observations_columns_kernel<APW, KT, CH>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return FLM_E_LAUNCH;
+  if (lds > 160 * 1024 - 512) return FLM_E_ARG;
+  if (lds > 64 * 1024) FLM_RAISE_LDS_ONCE((flm::observations_columns_kernel<APW, KT, CH>));
   hipLaunchKernelGGL((flm::observations_columns_kernel<APW, KT, CH>), grid, dim3(nw * 64), lds, stream, cols, A, T1,
                      plane_stride, obs);
   FLM_CHECK_LAUNCH();
@@ -737,8 +740,26 @@ extern "C" int flm_observations_req_columns(const int16_t* cols, const int32_t* 
   const int tile = plane_stride < FLM_REQ_TILE ? plane_stride : FLM_REQ_TILE;      // a multiple of 16
   dim3 grid((plane_stride + tile - 1) / tile, n_req);
   hipLaunchKernelGGL(flm::observations_req_columns_kernel, grid, dim3(256), 3 * (size_t)tile, (hipStream_t)stream, cols,
-                     req_agent, own_cols, own_row, A, T1, plane_stride, tile, out);
+                     req_agent, own_cols, own_row, A, T1, plane_stride, tile, nullptr, out);
   FLM_CHECK_LAUNCH();
+  return FLM_OK;
+}
+
+extern "C" int flm_observations_req_columns_rows(const int16_t* cols, const int32_t* req_agent, const int32_t* out_row,
+                                                 int n_req, int E, int A, int Rp, int T1, int plane_stride, uint8_t* out,
+                                                 void* stream) {
+  if (!cols || !req_agent || !out_row || !out) return FLM_E_ARG;
+  if (n_req <= 0 || E <= 0 || A <= 0 || A > 255 || Rp <= 0 || T1 <= 0 || plane_stride % 16 != 0 ||
+      (long long)plane_stride < (long long)Rp * T1)
+    return FLM_E_ARG;
+  const int tile = plane_stride < FLM_REQ_TILE ? plane_stride : FLM_REQ_TILE;      // a multiple of 16
+  for (int lo = 0; lo < n_req; lo += 65535) {                // the grid's y extent is 65,535
+    const int cnt = n_req - lo < 65535 ? n_req - lo : 65535;
+    dim3 grid((plane_stride + tile - 1) / tile, cnt);
+    hipLaunchKernelGGL(flm::observations_req_columns_kernel, grid, dim3(256), 3 * (size_t)tile, (hipStream_t)stream, cols,
+                       req_agent + lo, nullptr, nullptr, A, T1, plane_stride, tile, out_row + lo, out);
+    FLM_CHECK_LAUNCH();
+  }
   return FLM_OK;
 }
 
@@ -760,20 +781,18 @@ extern "C" int flm_reorder_rails(const uint8_t* obs_in, uint8_t* obs_out, int n,
 // FLM_BITMAPS_STATIC_MAX_COLS int16 entries (n_paths * T1 of one call): 4 MiB
 static __device__ __align__(256) int16_t scratch[FLM_BITMAPS_STATIC_MAX_COLS];
 
-#include <mutex>
-static std::mutex scratch_lock;
-static int16_t* scratch_ptr[64];        // per device ordinal; nullptr = not looked up yet
+static std::once_flag scratch_once[64];
+static int16_t* scratch_ptr[64];        // per device ordinal; nullptr = the look-up failed
 
-// Device address of this device's copy of `scratch` (each GPU holds its own copy at its own address).
+// Device address of this device's copy of `scratch` (each GPU holds its own copy at its own address), looked up
+// once per device with that device current.
 static int16_t* scratch_for_current_device() {
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  std::lock_guard<std::mutex> guard(scratch_lock);
-  if (!scratch_ptr[dev]) {
+  std::call_once(scratch_once[dev], [dev] {
     void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return nullptr;
-    scratch_ptr[dev] = static_cast<int16_t*>(p);
-  }
+    scratch_ptr[dev] = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) == hipSuccess ? static_cast<int16_t*>(p) : nullptr;
+  });
   return scratch_ptr[dev];
 }
 
@@ -790,4 +809,4 @@ extern "C" int flm_bitmaps_static(const int32_t* path_cell, const int32_t* path_
                      n_paths, H, W, capR, Rp, T1, plane_stride, Lcap, shift, ws, planes, err, stream);
 }
 
-extern "C" int flm_abi_version(void) { return 3; }
+extern "C" int flm_abi_version(void) { return 4; }

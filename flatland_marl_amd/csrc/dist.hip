@@ -421,12 +421,10 @@ extern "C" int flm_chain_index(const uint16_t* grid, const int32_t* cell_idx, co
   const size_t capS = (size_t)capCells * 4;
   size_t lds = capS * 6 + 16 + ((capS + 31) / 32 + 1) * 4 + 4 * (16 * 8 + 1) + 64;
   if (lds > 160 * 1024 - 512) return FLM_E_ARG;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(flm::chain_index_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)lds) != hipSuccess)
-    return FLM_E_LAUNCH;
+  FLM_RAISE_LDS_ONCE(flm::chain_index_kernel);
   hipLaunchKernelGGL(flm::chain_index_kernel, dim3(E), dim3(1024), lds, (hipStream_t)stream, grid, cell_idx, n_cells,
                      target_cell, A, H, W, capCells, capAnch, root, steps, edges, n_anchor, counts, succ, choice, walk,
-                     move_edge, move_succ, idx_cell, g_flm_stamps);
+                     move_edge, move_succ, idx_cell, flm_stamps_for(E));
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }
@@ -444,9 +442,7 @@ extern "C" int flm_distance_chains(const uint16_t* root, const uint16_t* steps, 
   if (capCells & 1) return FLM_E_ARG;     // 16-byte row stores
   size_t lds = (size_t)ldsAnch * (16 + 32 * 2);
   if (lds > 160 * 1024 - 512) return FLM_E_ARG;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(flm::distance_chain_kernel),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return FLM_E_LAUNCH;
+  FLM_RAISE_LDS_ONCE(flm::distance_chain_kernel);
   dim3 grid((A + 31) / 32, E);
   hipLaunchKernelGGL(flm::distance_chain_kernel, grid, dim3(FLM_DC_THREADS), lds, (hipStream_t)stream, root, steps, edges, n_anchor,
                      n_cells, cell_idx, slot_target, n_slots, A, H * W, capCells, capAnch, ldsAnch, dist, counts);

@@ -349,19 +349,9 @@ __global__ __launch_bounds__(512, 4) void gemm_x3_kernel(GemmArgs g) {
 template <bool A_KC, bool B_KC, int EPI>
 static int launch_gemm(const GemmArgs& g, int nz, hipStream_t stream) {
   dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, nz);
-  {
-    // the kernel's LDS size is raised once per device (the attribute belongs to the device's copy of the kernel)
-    static bool lds_set[64];
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return FLM_E_LAUNCH;
-    if (!lds_set[dev]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<A_KC, B_KC, EPI>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES) != hipSuccess)
-        return FLM_E_LAUNCH;
-      lds_set[dev] = true;
-    }
-    hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, EPI>), grid, dim3(512), X3_LDS_BYTES, stream, g);
-  }
+  // the kernel's LDS limit is raised once per device (the attribute belongs to the device's copy of the kernel)
+  FLM_RAISE_LDS_ONCE((gemm_x3_kernel<A_KC, B_KC, EPI>));
+  hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, EPI>), grid, dim3(512), X3_LDS_BYTES, stream, g);
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
 }
@@ -1145,9 +1135,7 @@ static int launch_conv_u8(const uint8_t* obs_u8, const float* Wc, const float* b
                           int plane_stride, long obs_bytes, float* x1, hipStream_t stream) {
   const size_t lds = conv_u8_lds(T1, NWAVE, BF);
   if (lds > 160 * 1024 - 512) return FLM_E_ARG;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8_kernel<WPL, NWAVE, BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)lds) != hipSuccess)
-    return FLM_E_LAUNCH;
+  FLM_RAISE_LDS_ONCE((conv_u8_kernel<WPL, NWAVE, BF>));
   // persistent workgroups: one per CU (256 CUs)
   const long tiles = (M + CV_TILE - 1) / CV_TILE;
   long wgs = (tiles + NWAVE - 1) / NWAVE;

@@ -3,9 +3,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/flmarl.h"
 
 #define FLM_WAVE 64
+
+// Raises a kernel's dynamic-LDS limit to what the CU has (160 KiB less the kernel's static LDS), once per device and
+// kernel, under std::call_once: the launch path makes no attribute call afterwards and concurrent host threads cannot
+// race on it.  Use inside an entry point (returns FLM_E_LAUNCH from it on failure); every use is a cache of its own.
+#define FLM_RAISE_LDS_ONCE(kernel)                                                                            \
+  do {                                                                                                        \
+    static std::once_flag flm_once_[64];                                                                      \
+    static bool flm_ok_[64];                                                                                  \
+    int flm_dev_ = -1;                                                                                        \
+    if (hipGetDevice(&flm_dev_) != hipSuccess || flm_dev_ < 0 || flm_dev_ >= 64) return FLM_E_LAUNCH;         \
+    std::call_once(flm_once_[flm_dev_], [&] { flm_ok_[flm_dev_] = flm::raise_lds_limit(reinterpret_cast<const void*>(kernel)); }); \
+    if (!flm_ok_[flm_dev_]) return FLM_E_LAUNCH;                                                              \
+  } while (0)
 
 #define FLM_CHECK_LAUNCH()                                  \
   do {                                                      \
@@ -13,6 +28,13 @@
   } while (0)
 
 namespace flm {
+
+inline bool raise_lds_limit(const void* kernel) {
+  hipFuncAttributes attr;
+  if (hipFuncGetAttributes(&attr, kernel) != hipSuccess) return false;
+  const int room = 160 * 1024 - (int)attr.sharedSizeBytes;
+  return room > 0 && hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, room) == hipSuccess;
+}
 
 __device__ __forceinline__ int dr(int h) { return (h == 0) ? -1 : ((h == 2) ? 1 : 0); }
 __device__ __forceinline__ int dc(int h) { return (h == 1) ? 1 : ((h == 3) ? -1 : 0); }
@@ -267,5 +289,7 @@ __device__ __forceinline__ int greedy_path(const uint16_t* __restrict__ grid, co
 // write shader-clock stamps at their phase boundaries to this device buffer, [3][E][16] 64-bit words
 // (0: anchor_decisions / walk_columns, 1: graph_build, 2: chain_index).  Nothing else reads it.
 extern unsigned long long* g_flm_stamps;
+extern int g_flm_stamps_envs;
+static inline unsigned long long* flm_stamps_for(int E) { return E <= g_flm_stamps_envs ? g_flm_stamps : nullptr; }
 
 

@@ -517,8 +517,13 @@ __global__ __launch_bounds__(FLM_WC_THREADS) void walk_columns_kernel(
 // Diagnostic hook (not part of the C ABI in include/): when set, every launch of flm_paths_columns, flm_graph_build
 // and flm_chain_index writes sixteen 64-bit words per environment to its third of the buffer ([3][E][16]): shader-clock
 // stamps at the phase boundaries and the rounds of one sweep.
+// The caller states how many environments the buffer was sized for; a launch over more environments gets no stamps.
 unsigned long long* g_flm_stamps = nullptr;
-extern "C" void flm_debug_fused_stamps(void* device_buffer) { g_flm_stamps = static_cast<unsigned long long*>(device_buffer); }
+int g_flm_stamps_envs = 0;
+extern "C" void flm_debug_fused_stamps(void* device_buffer, int capacity_envs) {
+  g_flm_stamps = static_cast<unsigned long long*>(device_buffer);
+  g_flm_stamps_envs = device_buffer ? capacity_envs : 0;
+}
 
 extern "C" long flm_paths_columns_lds_bytes(int A, int capCells, int ldsAnch, int ldsSlots, int capR, int Lcap, int T1) {
   if (A <= 0 || capCells <= 0 || ldsAnch <= 0 || ldsSlots <= 0 || capR <= 0 || Lcap <= 0 || T1 <= 0) return 0;
@@ -562,25 +567,22 @@ extern "C" int flm_paths_columns(const uint16_t* walk, const uint16_t* root, con
   int waves = (ldsSlots + FLM_TPG - 1) / FLM_TPG;
   waves = waves < 4 ? 4 : (waves > 16 ? 16 : waves);
   const bool alone = lds1 > 80 * 1024;   // one workgroup per CU anyway: a larger register budget costs nothing
-  const void* k1 = alone ? reinterpret_cast<const void*>(flm::anchor_decisions_kernel<13, 4>)
-                         : reinterpret_cast<const void*>(flm::anchor_decisions_kernel<10, 6>);
-  if (hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess) return FLM_E_LAUNCH;
+  if (alone) FLM_RAISE_LDS_ONCE((flm::anchor_decisions_kernel<13, 4>));
+  else FLM_RAISE_LDS_ONCE((flm::anchor_decisions_kernel<10, 6>));
   if (alone)
     hipLaunchKernelGGL((flm::anchor_decisions_kernel<13, 4>), dim3(E), dim3(waves * 64), lds1, stream, root, edges, move_edge,
                        n_anchor, cell_idx, tslot, n_slots, slot_target, start_cell, start_dir, A, H * W, capCells, capAnch,
-                       ldsAnch, ldsSlots, bits, reach, counts, g_flm_stamps);
+                       ldsAnch, ldsSlots, bits, reach, counts, flm_stamps_for(E));
   else
     hipLaunchKernelGGL((flm::anchor_decisions_kernel<10, 6>), dim3(E), dim3(waves * 64), lds1, stream, root, edges, move_edge,
                        n_anchor, cell_idx, tslot, n_slots, slot_target, start_cell, start_dir, A, H * W, capCells, capAnch,
-                       ldsAnch, ldsSlots, bits, reach, counts, g_flm_stamps);
+                       ldsAnch, ldsSlots, bits, reach, counts, flm_stamps_for(E));
   FLM_CHECK_LAUNCH();
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(flm::walk_columns_kernel),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total) != hipSuccess)
-    return FLM_E_LAUNCH;
+  FLM_RAISE_LDS_ONCE(flm::walk_columns_kernel);
   hipLaunchKernelGGL(flm::walk_columns_kernel, dim3(E), dim3(FLM_WC_THREADS), L.total, stream, walk, root, steps, move_edge,
                      move_succ, bits, reach, n_anchor, n_cells, n_slots, cell_idx, idx_cell, cell_rail, node_id, edge_info, counts, tslot,
                      start_cell, start_dir, pos_cell, target_cell, status, tpc, A, H, W, capCells, capAnch, ldsAnch, ldsSlots,
-                     capR, Rp, T1, max_depth, Lcap, shift, path_cell, path_meta, path_len, cols, err, g_flm_stamps);
+                     capR, Rp, T1, max_depth, Lcap, shift, path_cell, path_meta, path_len, cols, err, flm_stamps_for(E));
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }

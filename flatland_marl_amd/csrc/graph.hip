@@ -337,16 +337,15 @@ extern "C" int flm_graph_build(const uint16_t* grid, int E, int H, int W, int ca
   // stage the grid in LDS when two workgroups still fit a CU (80 KB each)
   const bool staged = lds_grid <= 80 * 1024;
   const size_t lds = staged ? lds_grid : lds_ports;
-  const void* fn = staged ? reinterpret_cast<const void*>(flm::graph_build_kernel<true>)
-                          : reinterpret_cast<const void*>(flm::graph_build_kernel<false>);
   if (lds > 160 * 1024 - 512) return FLM_E_ARG;
-  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return FLM_E_LAUNCH;
+  if (staged) FLM_RAISE_LDS_ONCE(flm::graph_build_kernel<true>);
+  else FLM_RAISE_LDS_ONCE(flm::graph_build_kernel<false>);
   if (staged)
     hipLaunchKernelGGL(flm::graph_build_kernel<true>, dim3(E), dim3(1024), lds, (hipStream_t)stream, grid, H, W, capN, capR,
-                       capC, node_id, node_cell, edge_info, edge_cell_off, edge_cells, cell_rail, counts, g_flm_stamps);
+                       capC, node_id, node_cell, edge_info, edge_cell_off, edge_cells, cell_rail, counts, flm_stamps_for(E));
   else
     hipLaunchKernelGGL(flm::graph_build_kernel<false>, dim3(E), dim3(1024), lds, (hipStream_t)stream, grid, H, W, capN, capR,
-                       capC, node_id, node_cell, edge_info, edge_cell_off, edge_cells, cell_rail, counts, g_flm_stamps);
+                       capC, node_id, node_cell, edge_info, edge_cell_off, edge_cells, cell_rail, counts, flm_stamps_for(E));
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }

@@ -120,7 +120,91 @@ __global__ __launch_bounds__(256) void replay_gather_kernel(const uint8_t* __res
   }
 }
 
+// ---- storing a rollout step's transitions (default replay feeding of the training script, src/main.py:275-278) ----
+// Request i of the step (the departing agents, then the agents in front of a switch) is stored when it had a row to
+// act on (sel_row[i] >= 0); the stored requests take consecutive ring slots from `head` on in request order; if there
+// are more of them than the ring holds, only the last `capacity` are kept (what appending to deque(maxlen) leaves).
+// One workgroup: count, then rank; writes slot[i] (-1 = not stored), the concatenated agent list, the three scalars
+// of every stored transition (the action after the crash checks, src/main.py:180,225; reward and done of the step)
+// and the number of transitions that the training loop counts (all of them, kept or not).
+__global__ __launch_bounds__(1024) void replay_store_index_kernel(
+    const int32_t* __restrict__ ready, int n_ready, const int32_t* __restrict__ sw, int n_switch,
+    const int32_t* __restrict__ sel_row, const int32_t* __restrict__ net, const double* __restrict__ reward,
+    const int32_t* __restrict__ done, int head, int capacity, int64_t* __restrict__ ring_action,
+    float* __restrict__ ring_reward, float* __restrict__ ring_done, int32_t* __restrict__ slot,
+    int32_t* __restrict__ req_out, int32_t* __restrict__ count_out) {
+  __shared__ int scratch[16];
+  const int tid = threadIdx.x, n = n_ready + n_switch;
+  int mine = 0;
+  for (int i = tid; i < n; i += 1024) mine += sel_row[i] >= 0 ? 1 : 0;
+  int total;
+  block_int_scan(mine, scratch, &total);
+  const int drop = total > capacity ? total - capacity : 0;
+  int base = 0;
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + tid;
+    const bool ok = i < n && sel_row[i] >= 0;
+    int tot;
+    const int rank = base + block_flag_scan(ok, scratch, &tot);
+    base += tot;
+    if (i < n) {
+      const int g = i < n_ready ? ready[i] : sw[i - n_ready];
+      req_out[i] = g;
+      int sl = -1;
+      if (ok && rank >= drop) {
+        sl = (int)(((long)head + rank - drop) % capacity);
+        ring_action[sl] = (int64_t)net[g];
+        ring_reward[sl] = (float)reward[g];
+        ring_done[sl] = done[g] ? 1.f : 0.f;
+      }
+      slot[i] = sl;
+    }
+  }
+  if (tid == 0) count_out[0] = total;
+}
+
+// One workgroup per (16 KiB piece of a row, request): the observation the agent acted on goes to its ring slot.
+__global__ __launch_bounds__(256) void replay_store_rows_kernel(const uint8_t* __restrict__ obs, const int32_t* __restrict__ sel_row,
+                                                                const int32_t* __restrict__ slot, long row_bytes,
+                                                                uint8_t* __restrict__ ring_state) {
+  const int i = blockIdx.y;
+  const int sl = slot[i];
+  if (sl < 0) return;
+  const uint8_t* src = obs + (long)sel_row[i] * row_bytes;
+  uint8_t* dst = ring_state + (long)sl * row_bytes;
+  const long lo = (long)blockIdx.x * 16384;
+  const long hi = lo + 16384 < row_bytes ? lo + 16384 : row_bytes;
+  for (long o = lo + (long)threadIdx.x * 16; o < hi; o += 256 * 16)
+    *reinterpret_cast<uint4*>(dst + o) = *reinterpret_cast<const uint4*>(src + o);
+}
+
 }  // namespace flm
+
+extern "C" int flm_replay_store(const int32_t* ready, int n_ready, const int32_t* sw, int n_switch, const int32_t* sel_row,
+                                const void* obs, long row_bytes, const int32_t* net, const double* reward,
+                                const int32_t* done, int head, int capacity, void* ring_state, int64_t* ring_action,
+                                float* ring_reward, float* ring_done, int32_t* slot, int32_t* req_out, int32_t* count_out,
+                                void* stream) {
+  if (!sel_row || !obs || !net || !reward || !done || !ring_state || !ring_action || !ring_reward || !ring_done || !slot ||
+      !req_out || !count_out || (n_ready > 0 && !ready) || (n_switch > 0 && !sw))
+    return FLM_E_ARG;
+  if (n_ready < 0 || n_switch < 0 || (long)n_ready + n_switch <= 0 || (long)n_ready + n_switch > 0x3FFFFFFF) return FLM_E_ARG;
+  if (capacity <= 0 || head < 0 || head >= capacity || row_bytes <= 0 || (row_bytes & 15)) return FLM_E_ARG;
+  if (((uintptr_t)obs | (uintptr_t)ring_state) & 15) return FLM_E_ARG;
+  const int n = n_ready + n_switch;
+  hipLaunchKernelGGL(flm::replay_store_index_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ready, n_ready, sw,
+                     n_switch, sel_row, net, reward, done, head, capacity, ring_action, ring_reward, ring_done, slot, req_out,
+                     count_out);
+  FLM_CHECK_LAUNCH();
+  const unsigned pieces = (unsigned)((row_bytes + 16383) / 16384);
+  for (int lo = 0; lo < n; lo += 65535) {                  // the grid's y extent is 65,535
+    const int cnt = n - lo < 65535 ? n - lo : 65535;
+    hipLaunchKernelGGL(flm::replay_store_rows_kernel, dim3(pieces, (unsigned)cnt), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t*)obs, sel_row + lo, slot + lo, row_bytes, (uint8_t*)ring_state);
+    FLM_CHECK_LAUNCH();
+  }
+  return FLM_OK;
+}
 
 extern "C" int flm_replay_sample(int size, int batch, uint32_t seed, uint32_t draw, int32_t* idx, void* stream) {
   if (!idx || size <= 0 || batch <= 0 || batch > size) return FLM_E_ARG;

@@ -383,9 +383,8 @@ extern "C" int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const
   } else {
     const int per_block = 64 / G;
     const size_t lds = (size_t)per_block * FLM_ALT_FRAME_INTS * sizeof(int);
-    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(flm::altpaths_kernel<false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return FLM_E_LAUNCH;
+    if (lds > 160 * 1024 - 512) return FLM_E_ARG;
+    FLM_RAISE_LDS_ONCE(flm::altpaths_kernel<false>);
     hipLaunchKernelGGL(flm::altpaths_kernel<false>, dim3((n_req + per_block - 1) / per_block), dim3(64), lds,
                        (hipStream_t)stream, grid, cell_idx, dist, succ, choice, tslot, node_id, req_agent, n_req, pos_cell,
                        direction, target_cell, A, H, W, capCells, max_depth, cap_alt, Lcap, G, alt_count, alt_len, alt_cell,

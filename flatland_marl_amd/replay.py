@@ -52,6 +52,32 @@ class DeviceReplay:
         self.head = (self.head + n) % self.capacity
         self.size = min(self.capacity, self.size + n)
 
+    def store_step(self, ro, req_ready, req_switch, sel_row, obs):
+        """The default feeding mode of the training script (src/main.py:275-278) for one rollout step of every
+        environment: the agents req_ready + req_switch that acted on row sel_row[i] >= 0 of obs [rows,3,plane_stride]
+        are stored with the decision left by the crash checks, the step's reward and done flag, and their
+        observation on the planes after the step, which flm_observations_req_columns_rows writes straight into
+        the ring.  Returns the number of transitions (one host read-back)."""
+        n1, n2 = req_ready.numel(), req_switch.numel()
+        n = n1 + n2
+        dev = self.device
+        if getattr(self, "_slot", None) is None or self._slot.numel() < n:
+            cap = max(n, 1024)
+            self._slot = torch.empty((cap,), dtype=torch.int32, device=dev)
+            self._req = torch.empty((cap,), dtype=torch.int32, device=dev)
+            self._count = torch.zeros((1,), dtype=torch.int32, device=dev)
+        b = ro.b
+        call("flm_replay_store", ptr(req_ready) if n1 else None, n1, ptr(req_switch) if n2 else None, n2, ptr(sel_row),
+             ptr(obs), self.row_bytes, ptr(ro.net), ptr(ro.reward), ptr(ro.done), self.head, self.capacity,
+             ptr(self.state), ptr(self.action), ptr(self.reward), ptr(self.done), ptr(self._slot), ptr(self._req),
+             ptr(self._count), ro.stream)
+        call("flm_observations_req_columns_rows", ptr(ro.cols), ptr(self._req), ptr(self._slot), n, ro.E, ro.A, b.Rp, b.T1,
+             b.plane_stride, ptr(self.next_state), ro.stream)
+        k = int(self._count.item())
+        self.head = (self.head + min(k, self.capacity)) % self.capacity
+        self.size = min(self.capacity, self.size + k)
+        return k
+
     def sample_indices(self, batch_size):
         """batch_size distinct entries, uniformly (src/agent.py:161)."""
         if batch_size > self.size:

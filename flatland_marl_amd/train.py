@@ -91,6 +91,12 @@ class DQNPolicy:
         return net, best
 
     @property
+    def raw(self):
+        """(departing agents, agents before a switch, observation rows, sel_row, sel_act) of the last step as the
+        kernels left them, or None when nobody consulted the network."""
+        return self._raw
+
+    @property
     def last(self):
         """[(agents, observations, actions)] of the agents that consulted the network in the last step and had
         something to choose from (src/main.py:163-165, 194, 213), or None."""
@@ -142,61 +148,77 @@ class BatchedTrainer:
         self.agent.learn_obs(self.replay.sample(self.agent.args.batch_size), self.agent.args.gamma, b.plane_stride)
         self.n_learn += 1
 
+    def _store_with_slots(self):
+        """The feeding modes that keep an observation per agent between steps: the crash penalty
+        (src/main.py:271-273) and switch-to-switch (src/main.py:280-296), and the default mode beside them."""
+        ro = self.ro
+        last = self.policy.last
+        n_new = 0
+        dev = ro.device
+        groups = [(r, o) for r, o, _ in (last or []) if r.numel()]
+        for req32, obs in groups:
+            self.curr_obs[req32.long()] = obs
+            self.has_curr[req32.long()] = True
+        if self.crash_penalty:                         # src/main.py:271-273: every agent whose check failed
+            idx = torch.nonzero((ro.crash.view(-1) != 0) & self.has_curr).view(-1)
+            k = idx.numel()
+            if k:
+                o = self.curr_obs[idx]
+                self.replay.add(o, torch.ones(k, dtype=torch.int64, device=dev),
+                                torch.full((k,), -100.0, device=dev), o, torch.ones(k, device=dev))
+                n_new += k
+        if not self.switch2switch:                     # src/main.py:275-278
+            for req32, obs in groups:
+                req = req32.long()
+                # the observation after the step: the agent's own plane against everybody's
+                next_obs = ro.consult_observations(req32.contiguous())
+                # the decision stored is the one after the crash checks (src/main.py:180, 225)
+                self.replay.add(obs, ro.net.view(-1)[req], ro.reward.view(-1)[req], next_obs, ro.done.view(-1)[req])
+                n_new += req.numel()
+        else:                                          # src/main.py:280-296
+            reward_all = ro.reward.view(-1)
+            if groups:
+                req = torch.cat([r for r, _ in groups]).long()
+                net_out = ro.net.view(-1)[req]
+                # an observation kept since the previous decision meets the current one
+                idx = req[self.has_buf[req]]
+                k = idx.numel()
+                if k:
+                    self.replay.add(self.buf_obs[idx], torch.ones(k, dtype=torch.int64, device=dev),
+                                    self.buf_rew[idx], self.curr_obs[idx], ro.done.view(-1)[idx])
+                    self.has_buf[idx] = False
+                    self.buf_rew[idx] = 0
+                    n_new += k
+                stop = req[net_out == 0]               # stored with action 1, as the script does (src/main.py:289)
+                k = stop.numel()
+                if k:
+                    o = self.curr_obs[stop]
+                    self.replay.add(o, torch.ones(k, dtype=torch.int64, device=dev), reward_all[stop], o,
+                                    torch.zeros(k, device=dev))
+                    n_new += k
+                go = req[net_out == 1]                 # kept until the agent's next decision
+                if go.numel():
+                    self.buf_obs[go] = self.curr_obs[go]
+                    self.has_buf[go] = True
+            self.buf_rew += torch.where(self.has_buf, reward_all, torch.zeros_like(reward_all))
+        return n_new
+
     def step(self, train=True):
         ro = self.ro
         self.policy.eps = self.eps
         ro.step(self.policy)
-        last = self.policy.last if train else None
         n_new = 0
-        if train and (last is not None or self.curr_obs is not None):
-            dev = ro.device
-            groups = [(r, o) for r, o, _ in (last or []) if r.numel()]
-            if self.curr_obs is not None:
-                for req32, obs in groups:
-                    self.curr_obs[req32.long()] = obs
-                    self.has_curr[req32.long()] = True
-            if self.crash_penalty:                         # src/main.py:271-273: every agent whose check failed
-                idx = torch.nonzero((ro.crash.view(-1) != 0) & self.has_curr).view(-1)
-                k = idx.numel()
-                if k:
-                    o = self.curr_obs[idx]
-                    self.replay.add(o, torch.ones(k, dtype=torch.int64, device=dev),
-                                    torch.full((k,), -100.0, device=dev), o, torch.ones(k, device=dev))
-                    n_new += k
-            if not self.switch2switch:                     # src/main.py:275-278
-                for req32, obs in groups:
-                    req = req32.long()
-                    # the observation after the step: the agent's own plane against everybody's
-                    next_obs = ro.consult_observations(req32.contiguous())
-                    # the decision stored is the one after the crash checks (src/main.py:180, 225)
-                    self.replay.add(obs, ro.net.view(-1)[req], ro.reward.view(-1)[req], next_obs, ro.done.view(-1)[req])
-                    n_new += req.numel()
-            else:                                          # src/main.py:280-296
-                reward_all = ro.reward.view(-1)
-                if groups:
-                    req = torch.cat([r for r, _ in groups]).long()
-                    net_out = ro.net.view(-1)[req]
-                    # an observation kept since the previous decision meets the current one
-                    idx = req[self.has_buf[req]]
-                    k = idx.numel()
-                    if k:
-                        self.replay.add(self.buf_obs[idx], torch.ones(k, dtype=torch.int64, device=dev),
-                                        self.buf_rew[idx], self.curr_obs[idx], ro.done.view(-1)[idx])
-                        self.has_buf[idx] = False
-                        self.buf_rew[idx] = 0
-                        n_new += k
-                    stop = req[net_out == 0]               # stored with action 1, as the script does (src/main.py:289)
-                    k = stop.numel()
-                    if k:
-                        o = self.curr_obs[stop]
-                        self.replay.add(o, torch.ones(k, dtype=torch.int64, device=dev), reward_all[stop], o,
-                                        torch.zeros(k, device=dev))
-                        n_new += k
-                    go = req[net_out == 1]                 # kept until the agent's next decision
-                    if go.numel():
-                        self.buf_obs[go] = self.curr_obs[go]
-                        self.has_buf[go] = True
-                self.buf_rew += torch.where(self.has_buf, reward_all, torch.zeros_like(reward_all))
+        if train and self.curr_obs is None:
+            # default feeding without per-agent observation slots (src/main.py:275-278): one pair of launches
+            # stores the whole batch's transitions, next-state observations written straight into the ring
+            raw = self.policy.raw
+            if raw is not None:
+                req1, req2, obs, sel_row, _ = raw
+                n_new = self.replay.store_step(ro, req1, req2, sel_row, obs)
+        elif train:
+            n_new = self._store_with_slots()
+        due = 0
+        if train:
             self.n_transitions += n_new
             # src/agent.py:57-67: one learn step per update_every stored transitions, once the memory is large enough
             due = (self.t_step + n_new) // self.agent.args.update_every
@@ -205,9 +227,6 @@ class BatchedTrainer:
                 due = min(due, self.max_learns_per_step)
             if len(self.replay) <= self.agent.args.batch_size:
                 due = 0
-        else:
-            due = 0
-        if train:
             # data parallel: every learn step all-reduces the gradient, so all ranks take the same number
             due = parallel.min_over_ranks(due, ro.device)
             for _ in range(due):

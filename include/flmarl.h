@@ -4,8 +4,13 @@
  * Every entry point takes plain device pointers, sizes and a HIP stream
  * (hipStream_t passed as void*), launches asynchronously on that stream and
  * returns 0 on success or a negative FLM_E_* code.  No entry point allocates
- * device memory or keeps state between calls.  One "batch" is E independent
- * environments of identical grid size H x W with A agents each.
+ * device memory, and none keeps per-call state: what the library remembers
+ * between calls is two one-time caches per device (that a kernel's dynamic
+ * LDS limit has been raised; the device address of flm_bitmaps_static's
+ * workspace array), both set once under std::call_once and never changed, and
+ * the diagnostic stamp buffer of flm_debug_fused_stamps when a caller sets it.
+ * One "batch" is E independent environments of identical grid size H x W with
+ * A agents each.
  *
  * Encodings shared by all calls
  *   heading        0..3 = N,E,S,W; a cell is r*W + c
@@ -246,6 +251,13 @@ int flm_observations_req_columns(const int16_t* cols, const int32_t* req_agent, 
                                  const int32_t* own_row, int n_req, int E, int A, int Rp, int T1, int plane_stride,
                                  uint8_t* out, void* stream);
 
+/* flm_observations_req_columns of the agents' own planes, written to chosen rows: request g goes to row
+ * out_row[g] of out [.,3,plane_stride] (a negative out_row[g] skips the request).  The training loop's
+ * next-state observations (get_obs on the planes after the step, src/main.py:277) go straight into the replay
+ * memory's ring this way.  Any n_req. */
+int flm_observations_req_columns_rows(const int16_t* cols, const int32_t* req_agent, const int32_t* out_row, int n_req,
+                                      int E, int A, int Rp, int T1, int plane_stride, uint8_t* out, void* stream);
+
 /* Rail reordering of finished observations.
  * Replaces ObsPreprocessor._reorder_rails / _swap_rails, src/preprocessing.py:32-59 (enabled by
  * --reorder-rails, src/main.py:395): the rails the own plane (plane 0) visits, in order of first visit,
@@ -429,6 +441,28 @@ int flm_replay_sample(int size, int batch, uint32_t seed, uint32_t draw, int32_t
 int flm_replay_gather(const void* state, const void* next_state, const int64_t* action, const float* reward,
                       const float* done, const int32_t* idx, int batch, long row_bytes, void* out_state, void* out_next,
                       int64_t* out_action, float* out_reward, float* out_done, void* stream);
+
+/* Storing one rollout step's transitions in the replay memory's ring.  Replaces the per-agent dqn.step(...) calls of
+ * the training script's default feeding mode, src/main.py:275-278 (-> ReplayBuffer.add, src/agent.py:153-157), for
+ * every environment of the batch at once.
+ *   ready [n_ready], sw [n_switch] int32   the agents (e*A + a) that consulted the network this step: departing
+ *                                          agents, then agents in front of a switch (flm_rollout_requests)
+ *   sel_row [n_ready+n_switch] int32       row of obs the agent acted on, -1 = it had nothing to choose from and
+ *                                          is not stored (flm_policy_select)
+ *   obs [.,row_bytes] bytes                the step's network rows (row_bytes % 16 == 0, 16-byte aligned)
+ *   net [E*A] int32, reward [E*A] double, done [E*A] int32   per agent after the step: the decision left by the
+ *                                          crash checks (src/main.py:180,225), the step's reward and done flag
+ *   head, capacity                         next ring slot to write and the ring's size
+ *   ring_state [capacity,row_bytes], ring_action int64 / ring_reward float / ring_done float [capacity]   the ring
+ * Stored requests take consecutive slots from head on (modulo capacity) in request order; when one step stores more
+ * than capacity, the last capacity are kept (deque(maxlen), src/agent.py:147).  Out: slot [n] int32 = ring slot of
+ * request i or -1; req_out [n] int32 = the concatenated agent list; count_out [1] int32 = transitions of the step
+ * (kept or not: what the learn cadence counts).  The next-state rows are then written with
+ * flm_observations_req_columns_rows(cols, req_out, slot, ...) into the ring's next-state array. */
+int flm_replay_store(const int32_t* ready, int n_ready, const int32_t* sw, int n_switch, const int32_t* sel_row,
+                     const void* obs, long row_bytes, const int32_t* net, const double* reward, const int32_t* done,
+                     int head, int capacity, void* ring_state, int64_t* ring_action, float* ring_reward,
+                     float* ring_done, int32_t* slot, int32_t* req_out, int32_t* count_out, void* stream);
 
 /* torch.optim.Adam step with default options over flat buffers (src/agent.py:38,113-115); step counts from 1. */
 int flm_dqn_adam(float* params, const float* grads, float* m, float* v, long n, double lr, double beta1, double beta2,

@@ -29,28 +29,44 @@ def test_graph_tables(name):
     assert np.array_equal(b.cell_rail[0].cpu().numpy(), g.cell_rail)
 
 
+# The two routes from a reset to the planes and observations.  "dense": distance maps -> shortest paths -> planes
+# -> observation kernel over dense planes (reset() + observations()).  "fused": the route the throughput figure is
+# measured on, reset_fused(): paths and columns straight from the chain index (flm_paths_columns) wherever the
+# tables fit the LDS, then the observations straight from the column form (flm_observations_columns).  Both meet
+# the reference's own outputs here.
+ROUTES = ["dense", "fused"]
+
+
+@pytest.mark.parametrize("route", ROUTES)
 @pytest.mark.parametrize("name", env_names())
-def test_distances_paths_maps_obs(name):
+def test_distances_paths_maps_obs(name, route):
+    import torch
     from oracle import oracle as orc
     depth = 150
     fx, gold = load_env(name), load_golden(name, depth)
     b = _batch(fx, depth)
-    b.reset()
     env = orc.OracleEnv(fx, depth)
-    # distances: compact uint16 -> dense int32, against the checker (and the golden hash)
-    cell_idx = b.cell_idx[0].cpu().numpy()
-    dist = b.dist[0].cpu().numpy().view(np.uint16)
-    tslot = b.tslot[0].cpu().numpy()
-    rail = cell_idx >= 0
-    dense = np.full((env.A, env.H * env.W, 4), -1, np.int32)
-    for a in range(env.A):
-        d = dist[tslot[a]].reshape(-1, 4)[cell_idx[rail]].astype(np.int32)
-        d[d == 0xFFFF] = -1
-        dense[a, rail] = d
-    dense = dense.reshape(env.A, env.H, env.W, 4)
-    for a in range(env.A):
-        assert np.array_equal(dense[a], env.dist(a)), (name, a)
-    assert sha(dense) == str(gold["dist_sha"])
+    if route == "fused":
+        obs = b.reset_fused()
+        b.check_graph()
+        # plane 0 of every observation is the dense occupancy plane
+        b.maps = obs[:, :, 0].contiguous().view(torch.int8)
+    else:
+        b.reset()
+        # distances: compact uint16 -> dense int32, against the checker (and the golden hash)
+        cell_idx = b.cell_idx[0].cpu().numpy()
+        dist = b.dist[0].cpu().numpy().view(np.uint16)
+        tslot = b.tslot[0].cpu().numpy()
+        rail = cell_idx >= 0
+        dense = np.full((env.A, env.H * env.W, 4), -1, np.int32)
+        for a in range(env.A):
+            d = dist[tslot[a]].reshape(-1, 4)[cell_idx[rail]].astype(np.int32)
+            d[d == 0xFFFF] = -1
+            dense[a, rail] = d
+        dense = dense.reshape(env.A, env.H, env.W, 4)
+        for a in range(env.A):
+            assert np.array_equal(dense[a], env.dist(a)), (name, a)
+        assert sha(dense) == str(gold["dist_sha"])
     # shortest paths against the golden (reference output)
     paths = b.paths_numpy(0)
     for a in range(env.A):
@@ -76,15 +92,19 @@ def test_distances_paths_maps_obs(name):
     assert not full[:, int(b.R[0]) * b.T1:].any()
 
 
+@pytest.mark.parametrize("route", ROUTES)
 @pytest.mark.parametrize("name", [n for n in env_names() if not str(load_golden(n)["error"])])
-def test_observations_golden(name):
+def test_observations_golden(name, route):
     import hashlib
     depth = 150
     fx, gold = load_env(name), load_golden(name, depth)
     Rp = int(gold["obs_rp"])
     b = _batch(fx, depth, max_rails=Rp)
-    b.reset()
-    b.observations()
+    if route == "fused":
+        b.reset_fused()
+    else:
+        b.reset()
+        b.observations()
     obs = b.obs_numpy(0)
     assert obs.shape == (b.A, 3, Rp, depth + 1)
     h = hashlib.sha256()

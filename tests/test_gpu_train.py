@@ -153,6 +153,92 @@ def test_replay_feeding_follows_the_script(s2s, penalty):
         assert any(x is not None for x in buffer_obs)
 
 
+def test_default_feeding_goes_through_the_store_kernel():
+    """The default mode (src/main.py:275-278) stores a step's transitions with flm_replay_store and writes the
+    next-state observations straight into the ring (flm_observations_req_columns_rows): the ring slots written by
+    every step, in order and across the wrap-around, against the script's per-agent rule."""
+    import torch
+    ro, agent, tr = _setup(E=3, A=12, depth=60, name="Test_2_Level_0", start_eps=0.4, replay_capacity=50)
+    agent.args.batch_size = 10 ** 9                           # never learn: only the feeding is under test
+    rp = tr.replay
+    assert tr.curr_obs is None
+    called = []
+    rp.add = lambda *a, **k: called.append(1)                # the tensor-by-tensor path must not run
+    total, wrapped = 0, 0
+    for t in range(70):
+        head, size = rp.head, rp.size
+        k = tr.step(train=True)
+        torch.cuda.synchronize()
+        want = []
+        for req, obs, _ in (tr.policy.last or []):
+            net = ro.net.view(-1)[req.long()].cpu().numpy()
+            rew = ro.reward.view(-1)[req.long()].to(torch.float32).cpu().numpy()
+            dn = ro.done.view(-1)[req.long()].cpu().numpy() != 0
+            nxt = ro.consult_observations(req.contiguous())
+            for j in range(req.numel()):
+                want.append((_hash(obs[j]), int(net[j]), float(rew[j]), _hash(nxt[j]), bool(dn[j])))
+        assert k == len(want), t
+        assert rp.head == (head + k) % rp.capacity and rp.size == min(rp.capacity, size + k)
+        wrapped += head + k > rp.capacity
+        for j, w in enumerate(want):
+            sl = (head + j) % rp.capacity
+            got = (_hash(rp.state[sl]), int(rp.action[sl]), float(rp.reward[sl]), _hash(rp.next_state[sl]),
+                   bool(rp.done[sl] != 0))
+            assert got == w, (t, j)
+        total += k
+    assert total > 100 and wrapped > 2 and not called
+
+
+def test_store_kernel_keeps_the_last_capacity_transitions_of_an_oversized_step():
+    """flm_replay_store through the C ABI with more stored requests than ring slots: slots, scalars and rows are those
+    of appending one by one to a deque(maxlen=capacity); requests without a row are skipped."""
+    import torch
+    from flatland_marl_amd._lib import call, ptr
+    dev = "cuda"
+    rng = np.random.default_rng(5)
+    n_agents, cap, head, row_bytes = 200, 23, 17, 64
+    perm = rng.permutation(n_agents)
+    ready, sw = np.sort(perm[:40]).astype(np.int32), np.sort(perm[40:101]).astype(np.int32)
+    n = len(ready) + len(sw)
+    rows = 150
+    sel_row = rng.integers(0, rows, n).astype(np.int32)
+    sel_row[rng.random(n) < 0.25] = -1
+    obs = rng.integers(0, 255, (rows, row_bytes)).astype(np.uint8)
+    net = rng.integers(0, 2, n_agents).astype(np.int32)
+    reward = -rng.random(n_agents)
+    done = (rng.random(n_agents) < 0.2).astype(np.int32)
+    d = {k: torch.as_tensor(v, device=dev) for k, v in dict(ready=ready, sw=sw, sel_row=sel_row, obs=obs, net=net,
+                                                             reward=reward, done=done).items()}
+    ring_state = torch.full((cap, row_bytes), 7, dtype=torch.uint8, device=dev)
+    ring_action = torch.full((cap,), -5, dtype=torch.int64, device=dev)
+    ring_reward = torch.full((cap,), 9.0, dtype=torch.float32, device=dev)
+    ring_done = torch.full((cap,), 9.0, dtype=torch.float32, device=dev)
+    slot = torch.empty((n,), dtype=torch.int32, device=dev)
+    req_out = torch.empty((n,), dtype=torch.int32, device=dev)
+    count = torch.zeros((1,), dtype=torch.int32, device=dev)
+    call("flm_replay_store", ptr(d["ready"]), len(ready), ptr(d["sw"]), len(sw), ptr(d["sel_row"]), ptr(d["obs"]), row_bytes,
+         ptr(d["net"]), ptr(d["reward"]), ptr(d["done"]), head, cap, ptr(ring_state), ptr(ring_action), ptr(ring_reward),
+         ptr(ring_done), ptr(slot), ptr(req_out), ptr(count), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    req = np.concatenate([ready, sw])
+    assert np.array_equal(req_out.cpu().numpy(), req)
+    ok = np.nonzero(sel_row >= 0)[0]
+    assert int(count.item()) == len(ok) > cap
+    from collections import deque
+    ring = deque(maxlen=cap)
+    for i in ok:
+        ring.append(i)
+    want_slot = np.full(n, -1, np.int32)
+    for j, i in enumerate(ring):
+        want_slot[i] = (head + j) % cap
+    assert np.array_equal(slot.cpu().numpy(), want_slot)
+    st, ac, rw, dn = (x.cpu().numpy() for x in (ring_state, ring_action, ring_reward, ring_done))
+    for i in ring:
+        sl, g = want_slot[i], req[i]
+        assert np.array_equal(st[sl], obs[sel_row[i]]) and ac[sl] == net[g] and rw[sl] == np.float32(reward[g])
+        assert dn[sl] == float(done[g] != 0)
+
+
 def test_policy_select_kernel():
     """flm_policy_select against numpy: greedy choice (eps = 0) is the first maximum over (alternative, action),
     exploring choices (eps = 1) are valid and spread out, sel_row / sel_act name the row acted on."""

@@ -26,9 +26,9 @@ need = _lib.query("flm_paths_columns_lds_bytes", A, b.cap_cells, b.lds_anchor, b
 print("cap_cells", b.cap_cells, "lds_anchor", b.lds_anchor, "lds_slots", b.lds_slots, "LDS bytes", need,
       "anchors max", int(b.n_anchor.max()), "slots max", int(b.n_slots.max()))
 st = torch.zeros((3, E, 16), dtype=torch.int64, device=b.device)
-lib.flm_debug_fused_stamps.argtypes = [ctypes.c_void_p]
+lib.flm_debug_fused_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 lib.flm_debug_fused_stamps.restype = None
-lib.flm_debug_fused_stamps(st.data_ptr())
+lib.flm_debug_fused_stamps(st.data_ptr(), E)
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 b.build_graph(sync=False)
 b.chain_index()
@@ -36,7 +36,7 @@ ev0.record()
 b.paths_columns_fused()
 ev1.record()
 torch.cuda.synchronize()
-lib.flm_debug_fused_stamps(None)
+lib.flm_debug_fused_stamps(None, 0)
 sall = st.cpu().numpy()
 s = sall[0]
 print("both kernels %.3f ms" % ev0.elapsed_time(ev1))
