@@ -117,11 +117,11 @@ class DQNAgent:
         d = dones.to(dev, torch.float32).contiguous()
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         self.optimizer.zero_grad()
-        call("flm_dqn_learn_grads", ptr(local), ptr(target), ptr(s), ptr(sn), ptr(a), ptr(r), ptr(d), float(gamma),
-             1 if self.double_dqn else 0, B, self.height, self.width, self.action_space, ptr(self._ws),
-             ptr(self.optimizer.grads), ptr(loss),
-             torch.cuda.current_stream(dev).cuda_stream)
-        parallel.allreduce_mean_(self.optimizer.grads)      # data parallel: one bucket, RCCL over xGMI
+        st = torch.cuda.current_stream(dev).cuda_stream
+        args = (ptr(local), ptr(target), ptr(s), ptr(sn), ptr(a), ptr(r), ptr(d), float(gamma),
+                1 if self.double_dqn else 0, B, self.height, self.width, self.action_space, ptr(self._ws),
+                ptr(self.optimizer.grads), ptr(loss))
+        self._grads_and_exchange("flm_dqn_learn_grads", args, st)
         self.last_loss = loss
         self._update(target)
 
@@ -147,13 +147,30 @@ class DQNAgent:
         d = dones.to(dev, torch.float32).contiguous()
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         self.optimizer.zero_grad()
-        call("flm_dqn_learn_grads_u8", ptr(local), ptr(target), ptr(s), ptr(sn), int(plane_stride), ptr(a), ptr(r), ptr(d),
-             float(gamma), 1 if self.double_dqn else 0, B, Rp, self.width, self.action_space, ptr(self._ws),
-             ptr(self.optimizer.grads), ptr(loss),
-             torch.cuda.current_stream(dev).cuda_stream)
-        parallel.allreduce_mean_(self.optimizer.grads)      # data parallel: one bucket, RCCL over xGMI
+        st = torch.cuda.current_stream(dev).cuda_stream
+        args = (ptr(local), ptr(target), ptr(s), ptr(sn), int(plane_stride), ptr(a), ptr(r), ptr(d),
+                float(gamma), 1 if self.double_dqn else 0, B, Rp, self.width, self.action_space, ptr(self._ws),
+                ptr(self.optimizer.grads), ptr(loss))
+        self._grads_and_exchange("flm_dqn_learn_grads_u8", args, st)
         self.last_loss = loss
         self._update(target)
+
+    def _grads_and_exchange(self, entry, args, stream):
+        """The gradients of one learn step and, with several ranks, their average over the ranks (the reference is a
+        single process, src/agent.py:14: one rank is its algorithm).  Data parallel: the step runs in two halves;
+        the gradients of the dense layers (98 % of the flat buffer) are final after the first and travel while the
+        second computes the convolution's, whose small sum follows; both are waited for before the optimizer."""
+        if not parallel.distributed():
+            call(entry, *args, stream)
+            return
+        grads = self.optimizer.grads
+        split = query("flm_dqn_grad_split", self.height, self.width, self.action_space)
+        ex = self.exchange = parallel.GradientExchange()
+        call(entry + "_phase", *args, 1, stream)
+        ex.begin(grads[split:])
+        call(entry + "_phase", *args, 2, stream)
+        ex.begin(grads[:split])
+        ex.finish()
 
     def _update(self, target):
         """optimizer.step() and soft_update (src/agent.py:113-118); one pass when soft_update is the class's own."""

@@ -1305,22 +1305,32 @@ extern "C" long flm_dqn_learn_workspace(int B, int H3, int T1, int NA) {
 // states (s, s_next) or uint8 observations (s_u8, sn_u8 with plane_stride): then the three forward passes read
 // the bytes and s points at workspace that receives the float copy of the states the convolution's weight
 // gradient needs.
-static int learn_grads_impl(const float* local, const float* target, const float* s, const float* s_next,
+// The step is written as two halves over one workspace.  The first: forward passes, loss, and the gradients of the
+// output layers and of the first dense layer (everything in grads from flm_dqn_grad_split() on: 98 % of the buffer,
+// complete and final).  The second: the gradient w.r.t. the convolution's activations and the convolution's own
+// gradients (the floats before the split).  A data-parallel caller sends the first part on its way between the two.
+struct LearnWorkspace {
+  float *x1, *hid, *x1n, *hidn, *x1t, *hidt, *dhid, *dx1, *cpart, *part, *q, *qn, *qt, *dq, *dadv, *dval, *sq;
+  LearnWorkspace(float* ws, int B, int H3, int T1, int NA) {
+    const long n_x1 = (long)B * 64 * H3, n_hid = (long)B * 1024;
+    x1 = ws;             hid = x1 + n_x1;
+    x1n = hid + n_hid;   hidn = x1n + n_x1;
+    x1t = hidn + n_hid;  hidt = x1t + n_x1;
+    dhid = hidt + n_hid;
+    dx1 = dhid + n_hid;
+    cpart = dx1 + n_x1;
+    part = cpart + (long)B * 64 * T1;
+    q = part + (long)fc1_k_slices(B) * B * 1024;
+    qn = q + (long)NA * B; qt = qn + (long)NA * B; dq = qt + (long)NA * B;
+    dadv = dq + (long)NA * B; dval = dadv + (long)NA * B; sq = dval + B;
+  }
+};
+
+static int learn_dense_half(const float* local, const float* target, const float* s, const float* s_next,
                             const uint8_t* s_u8, const uint8_t* sn_u8, int plane_stride, const int64_t* action,
                             const float* reward, const float* done, float gamma, int double_dqn, int B, int H3, int T1,
-                            int NA, float* ws, float* grads, float* loss_out, hipStream_t stream) {
+                            int NA, const LearnWorkspace& w, float* grads, float* loss_out, hipStream_t stream) {
   DqnLayout L(H3, T1, NA);
-  const long n_x1 = (long)B * 64 * H3, n_hid = (long)B * 1024;
-  float* x1 = ws;            float* hid = x1 + n_x1;
-  float* x1n = hid + n_hid;  float* hidn = x1n + n_x1;
-  float* x1t = hidn + n_hid; float* hidt = x1t + n_x1;
-  float* dhid = hidt + n_hid;
-  float* dx1 = dhid + n_hid;
-  float* cpart = dx1 + n_x1;
-  float* part = cpart + (long)B * 64 * T1;
-  float* q = part + (long)fc1_k_slices(B) * B * 1024;
-  float* qn = q + (long)NA * B; float* qt = qn + (long)NA * B; float* dq = qt + (long)NA * B;
-  float* dadv = dq + (long)NA * B; float* dval = dadv + (long)NA * B; float* sq = dval + B;
   int rc;
   if (s_u8) {
     if ((long)B * 3 > 65535) return FLM_E_ARG;
@@ -1328,43 +1338,51 @@ static int learn_grads_impl(const float* local, const float* target, const float
                        H3 / 3, T1, plane_stride, const_cast<float*>(s));
     if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   }
-  if ((rc = dqn_forward_impl(local, s_u8 ? nullptr : s, s_u8, plane_stride, B, H3, T1, NA, x1, hid, part, q, stream))) return rc;
-  // the local network's view of the next states picks the action only under double DQN
-  if (double_dqn &&
-      (rc = dqn_forward_impl(local, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, NA, x1n, hidn, part, qn, stream)))
+  if ((rc = dqn_forward_impl(local, s_u8 ? nullptr : s, s_u8, plane_stride, B, H3, T1, NA, w.x1, w.hid, w.part, w.q, stream)))
     return rc;
-  if ((rc = dqn_forward_impl(target, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, NA, x1t, hidt, part, qt, stream)))
+  // the local network's view of the next states picks the action only under double DQN
+  if (double_dqn && (rc = dqn_forward_impl(local, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, NA, w.x1n, w.hidn,
+                                           w.part, w.qn, stream)))
+    return rc;
+  if ((rc = dqn_forward_impl(target, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, NA, w.x1t, w.hidt, w.part, w.qt,
+                             stream)))
     return rc;
   if (double_dqn)
-    hipLaunchKernelGGL(flm::td_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, q, qn, qt, action, reward, done,
-                       gamma, B, NA, dq, sq);
+    hipLaunchKernelGGL(flm::td_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, w.q, w.qn, w.qt, action, reward, done,
+                       gamma, B, NA, w.dq, w.sq);
   else
-    hipLaunchKernelGGL(flm::td_loss_plain_kernel, dim3(1), dim3(1024), 0, stream, q, qt, action, reward, done, gamma, B, NA,
-                       dq, sq);
-  hipLaunchKernelGGL(flm::mean_kernel, dim3(1), dim3(64), 0, stream, sq, B, loss_out);
+    hipLaunchKernelGGL(flm::td_loss_plain_kernel, dim3(1), dim3(1024), 0, stream, w.q, w.qt, action, reward, done, gamma, B,
+                       NA, w.dq, w.sq);
+  hipLaunchKernelGGL(flm::mean_kernel, dim3(1), dim3(64), 0, stream, w.sq, B, loss_out);
   // head
-  hipLaunchKernelGGL(flm::head_backward_hidden_kernel, dim3(B), dim3(64), 0, stream, hid, dq, local + L.a2_w, local + L.v2_w, B,
-                     NA, dhid, dadv, dval);
-  hipLaunchKernelGGL(flm::head_backward_params_kernel, dim3(8, NA + 1), dim3(1024), 0, stream, hid, dadv, dval, B, NA,
+  hipLaunchKernelGGL(flm::head_backward_hidden_kernel, dim3(B), dim3(64), 0, stream, w.hid, w.dq, local + L.a2_w,
+                     local + L.v2_w, B, NA, w.dhid, w.dadv, w.dval);
+  hipLaunchKernelGGL(flm::head_backward_params_kernel, dim3(8, NA + 1), dim3(1024), 0, stream, w.hid, w.dadv, w.dval, B, NA,
                      grads + L.a2_w, grads + L.a2_b, grads + L.v2_w, grads + L.v2_b);
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   // first dense layer: weight gradients dW[n,j] = sum_b dhid[b,n] * x1[b,j], both streams as two groups of one launch
   // (more workgroups per launch: fewer idle matrix pipes in the last round); bias gradients = column sums
-  {
-    GemmArgs g{};
-    g.A = dhid; g.B = x1; g.C = grads + L.a1_w;
-    g.M = 512; g.N = (int)L.K1; g.K = B; g.lda = 1024; g.ldb = L.K1; g.ldc = L.K1;
-    g.ksplit = B; g.groups = 2; g.a_zs = 512; g.b_zs = 0; g.c_zs = 0; g.c_gs = L.v1_w - L.a1_w; g.x_slowest = 1;
-    if ((rc = flm::launch_gemm<false, false, flm::EPI_PLAIN>(g, 2, stream))) return rc;
-    for (int st = 0; st < 2; st++)
-      hipLaunchKernelGGL(flm::colsum_kernel, dim3(8), dim3(1024), 0, stream, dhid + st * 512, B, 512, 1024L,
-                         grads + (st ? L.v1_b : L.a1_b));
-  }
+  GemmArgs g{};
+  g.A = w.dhid; g.B = w.x1; g.C = grads + L.a1_w;
+  g.M = 512; g.N = (int)L.K1; g.K = B; g.lda = 1024; g.ldb = L.K1; g.ldc = L.K1;
+  g.ksplit = B; g.groups = 2; g.a_zs = 512; g.b_zs = 0; g.c_zs = 0; g.c_gs = L.v1_w - L.a1_w; g.x_slowest = 1;
+  if ((rc = flm::launch_gemm<false, false, flm::EPI_PLAIN>(g, 2, stream))) return rc;
+  for (int st = 0; st < 2; st++)
+    hipLaunchKernelGGL(flm::colsum_kernel, dim3(8), dim3(1024), 0, stream, w.dhid + st * 512, B, 512, 1024L,
+                       grads + (st ? L.v1_b : L.a1_b));
+  if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
+  return FLM_OK;
+}
+
+static int learn_conv_half(const float* local, const float* s, int B, int H3, int T1, int NA, const LearnWorkspace& w,
+                           float* grads, hipStream_t stream) {
+  DqnLayout L(H3, T1, NA);
+  int rc;
   // gradient w.r.t. the conv activations: dx1 = [dhid_adv dhid_val] * [W_adv; W_val], zero where x1 == 0: one product
   // over K = 1024 (the two weight blocks are not adjacent: the value block starts v1_w - a1_w - 512*K1 floats late)
   {
     GemmArgs g{};
-    g.A = dhid; g.B = local + L.a1_w; g.C = dx1; g.mask = x1;
+    g.A = w.dhid; g.B = local + L.a1_w; g.C = w.dx1; g.mask = w.x1;
     g.M = B; g.N = (int)L.K1; g.K = 1024; g.lda = 1024; g.ldb = L.K1; g.ldc = L.K1;
     g.b_break_k = 512; g.b_break_off = (L.v1_w - L.a1_w) - 512L * L.K1; g.x_slowest = 1;
     if ((rc = flm::launch_gemm<true, false, flm::EPI_MASK>(g, 1, stream))) return rc;
@@ -1372,19 +1390,33 @@ static int learn_grads_impl(const float* local, const float* target, const float
   // conv weights: per sample dWc_b[64,T1] = dx1_b[64,H3] * s_b[H3,T1], then a fixed-order sum over the batch
   {
     GemmArgs g{};
-    g.A = dx1; g.B = s; g.C = cpart;
+    g.A = w.dx1; g.B = s; g.C = w.cpart;
     g.M = 64; g.N = T1; g.K = H3; g.lda = H3; g.ldb = T1; g.ldc = T1;
     g.a_zs = 64L * H3; g.b_zs = (long)H3 * T1; g.c_zs = 64L * T1;
     if ((rc = flm::launch_gemm<true, false, flm::EPI_PLAIN>(g, B, stream))) return rc;
     const long ne = 64L * T1;
-    hipLaunchKernelGGL(flm::reduce_partials_kernel, dim3((unsigned)((ne + 63) / 64)), dim3(1024), 0, stream, cpart, B, ne,
+    hipLaunchKernelGGL(flm::reduce_partials_kernel, dim3((unsigned)((ne + 63) / 64)), dim3(1024), 0, stream, w.cpart, B, ne,
                        grads + L.conv_w);
     // bias: four interleaved parts of the batch side by side (cpart is free again: stream order), then their sum
-    hipLaunchKernelGGL(flm::conv_bias_grad_kernel, dim3(64, 4), dim3(1024), 0, stream, dx1, B, H3, cpart);
-    hipLaunchKernelGGL(flm::reduce_partials_kernel, dim3(1), dim3(1024), 0, stream, cpart, 4, 64L, grads + L.conv_b);
+    hipLaunchKernelGGL(flm::conv_bias_grad_kernel, dim3(64, 4), dim3(1024), 0, stream, w.dx1, B, H3, w.cpart);
+    hipLaunchKernelGGL(flm::reduce_partials_kernel, dim3(1), dim3(1024), 0, stream, w.cpart, 4, 64L, grads + L.conv_b);
   }
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
+}
+
+// phase 0: the whole step; 1: the first half; 2: the second half (same arguments, workspace untouched in between)
+static int learn_grads_impl(const float* local, const float* target, const float* s, const float* s_next,
+                            const uint8_t* s_u8, const uint8_t* sn_u8, int plane_stride, const int64_t* action,
+                            const float* reward, const float* done, float gamma, int double_dqn, int B, int H3, int T1,
+                            int NA, float* ws, float* grads, float* loss_out, hipStream_t stream, int phase = 0) {
+  const LearnWorkspace w(ws, B, H3, T1, NA);
+  int rc = FLM_OK;
+  if (phase != 2)
+    rc = learn_dense_half(local, target, s, s_next, s_u8, sn_u8, plane_stride, action, reward, done, gamma, double_dqn, B, H3,
+                          T1, NA, w, grads, loss_out, stream);
+  if (rc == FLM_OK && phase != 1) rc = learn_conv_half(local, s, B, H3, T1, NA, w, grads, stream);
+  return rc;
 }
 
 extern "C" int flm_dqn_learn_grads(const float* local, const float* target, const float* s, const float* s_next,
@@ -1395,6 +1427,19 @@ extern "C" int flm_dqn_learn_grads(const float* local, const float* target, cons
   if (B <= 0 || H3 <= 0 || T1 <= 0 || !actions_ok(NA)) return FLM_E_ARG;
   return learn_grads_impl(local, target, s, s_next, nullptr, nullptr, 0, action, reward, done, gamma, double_dqn, B, H3, T1,
                           NA, ws, grads, loss_out, (hipStream_t)stream);
+}
+
+// first float of grads that phase 1 of a split learn step completes (the convolution's gradients lie before it)
+extern "C" long flm_dqn_grad_split(int H3, int T1, int NA) { return actions_ok(NA) ? DqnLayout(H3, T1, NA).a1_w : 0; }
+
+extern "C" int flm_dqn_learn_grads_phase(const float* local, const float* target, const float* s, const float* s_next,
+                                         const int64_t* action, const float* reward, const float* done, float gamma,
+                                         int double_dqn, int B, int H3, int T1, int NA, float* ws, float* grads,
+                                         float* loss_out, int phase, void* stream) {
+  if (!local || !target || !s || !s_next || !action || !reward || !done || !ws || !grads || !loss_out) return FLM_E_ARG;
+  if (B <= 0 || H3 <= 0 || T1 <= 0 || !actions_ok(NA) || phase < 1 || phase > 2) return FLM_E_ARG;
+  return learn_grads_impl(local, target, s, s_next, nullptr, nullptr, 0, action, reward, done, gamma, double_dqn, B, H3, T1,
+                          NA, ws, grads, loss_out, (hipStream_t)stream, phase);
 }
 
 extern "C" long flm_dqn_learn_workspace_u8(int B, int Rp, int T1, int NA) {
@@ -1412,6 +1457,19 @@ extern "C" int flm_dqn_learn_grads_u8(const float* local, const float* target, c
   float* s_f32 = ws + flm_dqn_learn_workspace(B, H3, T1, NA);   // the float copy of s lives behind the common workspace
   return learn_grads_impl(local, target, s_f32, nullptr, s, s_next, plane_stride, action, reward, done, gamma, double_dqn, B,
                           H3, T1, NA, ws, grads, loss_out, (hipStream_t)stream);
+}
+
+extern "C" int flm_dqn_learn_grads_u8_phase(const float* local, const float* target, const uint8_t* s, const uint8_t* s_next,
+                                            int plane_stride, const int64_t* action, const float* reward,
+                                            const float* done, float gamma, int double_dqn, int B, int Rp, int T1, int NA,
+                                            float* ws, float* grads, float* loss_out, int phase, void* stream) {
+  if (!local || !target || !s || !s_next || !action || !reward || !done || !ws || !grads || !loss_out) return FLM_E_ARG;
+  if (B <= 0 || Rp <= 0 || T1 <= 0 || (long)plane_stride < (long)Rp * T1 || !actions_ok(NA) || phase < 1 || phase > 2)
+    return FLM_E_ARG;
+  const int H3 = 3 * Rp;
+  float* s_f32 = ws + flm_dqn_learn_workspace(B, H3, T1, NA);
+  return learn_grads_impl(local, target, s_f32, nullptr, s, s_next, plane_stride, action, reward, done, gamma, double_dqn, B,
+                          H3, T1, NA, ws, grads, loss_out, (hipStream_t)stream, phase);
 }
 
 extern "C" int flm_dqn_adam(float* params, const float* grads, float* m, float* v, long n, double lr, double beta1,

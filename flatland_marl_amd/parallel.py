@@ -75,3 +75,39 @@ def allreduce_mean_(flat):
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.div_(dist.get_world_size())
     return flat
+
+
+def distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class GradientExchange:
+    """The data-parallel gradient exchange of one learn step, started in two parts so that the first travels while
+    the backward pass is still computing the second: begin(part) starts the sum of a slice of the flat gradient
+    buffer over all ranks without waiting for it, finish() waits for every part and divides by the number of ranks.
+    With RCCL the sums run on the communicator's stream, ordered behind the kernels enqueued so far; with gloo
+    (rehearsal on the CPU, or several ranks on one GPU) a part is staged through the host and summed by the
+    backend's own thread.  `parts` records what was reduced (tests)."""
+
+    def __init__(self):
+        self._pending = []
+        self.parts = []
+
+    def begin(self, part):
+        if not distributed():
+            return
+        self.parts.append((part.data_ptr(), part.numel()))
+        if part.is_cuda and dist.get_backend() == "gloo":
+            host = part.cpu()
+            self._pending.append((dist.all_reduce(host, op=dist.ReduceOp.SUM, async_op=True), part, host))
+        else:
+            self._pending.append((dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=True), part, None))
+
+    def finish(self):
+        world = dist.get_world_size() if distributed() else 1
+        for work, part, host in self._pending:
+            work.wait()
+            if host is not None:
+                part.copy_(host)
+            part.div_(world)
+        self._pending = []

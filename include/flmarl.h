@@ -429,6 +429,22 @@ int flm_dqn_learn_grads_u8(const float* local, const float* target, const uint8_
                            int double_dqn, int B, int Rp, int T1, int NA, float* workspace, float* grads,
                            float* loss_out, void* stream);
 
+/* The same learn step in two calls, for a data-parallel caller that overlaps the gradient exchange with the
+ * backward pass (no counterpart in the reference, which is a single process, src/agent.py:14).  phase 1: forward
+ * passes, loss, and every gradient from float flm_dqn_grad_split(H3, T1, NA) of grads on (output layers and first
+ * dense layer: final values); phase 2, with the same arguments and the workspace untouched in between: the floats
+ * before the split (the convolution's weight and bias gradients).  Both phases together launch exactly the kernels of
+ * the one-call form in the same order: the same bits. */
+long flm_dqn_grad_split(int H3, int T1, int NA);
+int flm_dqn_learn_grads_phase(const float* local, const float* target, const float* s, const float* s_next,
+                              const int64_t* action, const float* reward, const float* done, float gamma, int double_dqn,
+                              int B, int H3, int T1, int NA, float* workspace, float* grads, float* loss_out, int phase,
+                              void* stream);
+int flm_dqn_learn_grads_u8_phase(const float* local, const float* target, const uint8_t* s, const uint8_t* s_next,
+                                 int plane_stride, const int64_t* action, const float* reward, const float* done,
+                                 float gamma, int double_dqn, int B, int Rp, int T1, int NA, float* workspace,
+                                 float* grads, float* loss_out, int phase, void* stream);
+
 /* Uniform sampling without replacement from a replay memory that lives in device memory, and the gather of the
  * sampled transitions.  Replaces ReplayBuffer.sample, src/agent.py:159-174 (random.sample over the deque, then
  * one stacked tensor per field).

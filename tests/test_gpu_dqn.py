@@ -469,3 +469,46 @@ def test_plain_dqn_matches_reference_golden():
         want = p.grad.reshape(-1).numpy()
         assert close(flat[off:off + want.size], want, rtol=2e-5)
         off += want.size
+
+
+@pytest.mark.parametrize("u8", [False, True])
+def test_learn_step_in_two_phases_gives_the_same_bits(u8):
+    """flm_dqn_learn_grads(_u8)_phase 1 then 2 = the one-call form bit for bit, and the dense layers' gradients are
+    already final after phase 1 (what a data-parallel caller sends while phase 2 runs)."""
+    from flatland_marl_amd._lib import call, ptr, query
+    dev = "cuda"
+    B, Rp, T1, NA = 70, 12, 37, 2
+    H3 = 3 * Rp
+    ps = (Rp * T1 + 255) // 256 * 256
+    g = torch.Generator().manual_seed(5)
+    n = query("flm_dqn_param_count", H3, T1, NA)
+    local = (torch.randn(n, generator=g) * 0.05).to(dev)
+    target = (torch.randn(n, generator=g) * 0.05).to(dev)
+    act = torch.randint(0, NA, (B,), generator=g).to(dev)
+    rew = torch.randn(B, generator=g).to(dev)
+    done = (torch.rand(B, generator=g) < 0.2).float().to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    split = query("flm_dqn_grad_split", H3, T1, NA)
+    assert split == 64 * T1 + 64
+    if u8:
+        s8 = torch.randint(0, 3, (B, 3, ps), generator=g, dtype=torch.uint8).to(dev)
+        sn8 = torch.randint(0, 3, (B, 3, ps), generator=g, dtype=torch.uint8).to(dev)
+        ws = torch.empty(query("flm_dqn_learn_workspace_u8", B, Rp, T1, NA), device=dev)
+        head = (ptr(local), ptr(target), ptr(s8), ptr(sn8), ps, ptr(act), ptr(rew), ptr(done), 0.97, 1, B, Rp, T1, NA, ptr(ws))
+        name = "flm_dqn_learn_grads_u8"
+    else:
+        s = torch.randint(-1, 3, (B, H3, T1), generator=g).float().to(dev)
+        sn = torch.randint(-1, 3, (B, H3, T1), generator=g).float().to(dev)
+        ws = torch.empty(query("flm_dqn_learn_workspace", B, H3, T1, NA), device=dev)
+        head = (ptr(local), ptr(target), ptr(s), ptr(sn), ptr(act), ptr(rew), ptr(done), 0.97, 1, B, H3, T1, NA, ptr(ws))
+        name = "flm_dqn_learn_grads"
+    want, loss_w = torch.zeros(n, device=dev), torch.zeros(1, device=dev)
+    call(name, *head, ptr(want), ptr(loss_w), st)
+    got, loss_g = torch.full((n,), 3.0, device=dev), torch.zeros(1, device=dev)
+    call(name + "_phase", *head, ptr(got), ptr(loss_g), 1, st)
+    torch.cuda.synchronize()
+    assert torch.equal(got[split:], want[split:]) and torch.equal(loss_g, loss_w)
+    assert bool((got[:split] == 3.0).all())                   # phase 1 leaves the convolution's gradients alone
+    call(name + "_phase", *head, ptr(got), ptr(loss_g), 2, st)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)

@@ -51,7 +51,10 @@ def _worker(rank, world, port, out_dir):
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), w=w.cpu().numpy(), changed=float((w - w0).abs().max().item()),
              learns=out["learns"], transitions=out["transitions"], steps=out["steps"],
              target=agent.qnetwork_target.flat_params().cpu().numpy(), start=data["start"], goal=data["target"],
-             final_pos=ro.pos.cpu().numpy(), flagged=out["agents_flagged"])
+             final_pos=ro.pos.cpu().numpy(), flagged=out["agents_flagged"],
+             parts=np.array([n for _, n in agent.exchange.parts], np.int64),
+             part_offsets=np.array([(p - agent.optimizer.grads.data_ptr()) // 4 for p, _ in agent.exchange.parts], np.int64),
+             n_params=w.numel())
     dist.destroy_process_group()
 
 
@@ -67,5 +70,10 @@ def test_two_ranks_keep_identical_weights(tmp_path):
     assert not np.array_equal(r[0]["final_pos"], r[1]["final_pos"])
     assert int(r[0]["transitions"]) > 0 and int(r[1]["transitions"]) > 0
     assert float(r[0]["changed"]) > 0
+    # the exchange went in two parts that tile the flat gradient: dense layers first (while the convolution's
+    # gradients were still being computed), then the convolution's
+    for i in range(world):
+        n, conv = int(r[i]["n_params"]), 64 * 41 + 64
+        assert r[i]["parts"].tolist() == [n - conv, conv] and r[i]["part_offsets"].tolist() == [conv, 0]
     assert np.array_equal(r[0]["w"], r[1]["w"])                     # same averaged gradient, same Adam state
     assert np.array_equal(r[0]["target"], r[1]["target"])

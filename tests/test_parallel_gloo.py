@@ -31,7 +31,14 @@ def _worker(rank, world, port, n_total, out_dir):
     fewest = parallel.min_over_ranks(3 + 2 * rank)
     g = torch.full((1000,), float(rank + 1))
     parallel.allreduce_mean_(g)
+    # the learn step's exchange in two parts: both are started before either is waited for
+    g2 = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    ex = parallel.GradientExchange()
+    ex.begin(g2[100:])
+    ex.begin(g2[:100])
+    ex.finish()
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), lo=lo, hi=hi, t=t, total=total, fewest=fewest, g=g.numpy(),
+             g2=g2.numpy(), g2_parts=np.array([n for _, n in ex.parts]),
              start=mine["start"], target=mine["target"], grid=mine["grid"], speed=mine["speed"],
              direction=mine["direction"])
     dist.destroy_process_group()
@@ -47,6 +54,8 @@ def test_two_ranks_shard_and_reduce(tmp_path):
     assert float(r[0]["total"]) == float(r[1]["total"]) == n_total
     assert int(r[0]["fewest"]) == int(r[1]["fewest"]) == 3          # learn steps every rank can take together
     assert np.allclose(r[0]["g"], 1.5) and np.allclose(r[1]["g"], 1.5)
+    for i in range(world):
+        assert np.array_equal(r[i]["g2"], np.arange(1000, dtype=np.float32) * 1.5) and r[i]["g2_parts"].tolist() == [900, 100]
     # shards are what a single process would have built for the same global environment indices
     from flatland_marl_amd.synthetic import make_batch
     fx = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "envs", "Test_0_Level_0.npz")))
