@@ -626,6 +626,78 @@ __global__ __launch_bounds__(64) void head_forward_kernel(const float* __restric
   }
 }
 
+// The split-K reduction of the first dense layer (both streams) with its bias and ReLU, then the output layers and
+// the dueling combination: reduce_bias_relu_kernel and head_forward_kernel in one launch, one workgroup per sample.
+// Thread t owns hidden units 4t..4t+3 (threads 0..127 the advantage stream, 128..255 the value stream): it sums
+// their K slices in slice order (the same bits as reduce_bias_relu_kernel), stores them, and multiplies them with
+// its four columns of the output weights; lanes meet in the wave, the four waves in LDS, in a fixed order.
+// part, hid and the two bias vectors must be 16-byte aligned.
+__global__ __launch_bounds__(256) void fc1_reduce_head_kernel(const float* __restrict__ part, int nz, int B,
+                                                              const float* __restrict__ bias_a, const float* __restrict__ bias_v,
+                                                              float* __restrict__ hid, const float* __restrict__ a2w,
+                                                              const float* __restrict__ a2b, const float* __restrict__ v2w,
+                                                              const float* __restrict__ v2b, int NA, float* __restrict__ q) {
+  __shared__ float red[4][FLM_DQN_MAX_ACTIONS];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const long slice = (long)B * 256;                                      // float4 per K slice
+  const float4* p = reinterpret_cast<const float4*>(part) + (long)b * 256 + t;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  int z = 0;
+  for (; z + 4 <= nz; z += 4) {                                          // four loads in flight, added in slice order
+    const float4 v0 = p[(long)z * slice], v1 = p[(long)(z + 1) * slice], v2 = p[(long)(z + 2) * slice],
+                 v3 = p[(long)(z + 3) * slice];
+    s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+    s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+    s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+    s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+  }
+  for (; z < nz; z++) {
+    const float4 v0 = p[(long)z * slice];
+    s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+  }
+  const bool adv = t < 128;
+  const int u = adv ? 4 * t : 4 * (t - 128);                             // first of the thread's units inside its stream
+  const float4 bb = *reinterpret_cast<const float4*>((adv ? bias_a : bias_v) + u);
+  s.x = fmaxf(s.x + bb.x, 0.f); s.y = fmaxf(s.y + bb.y, 0.f); s.z = fmaxf(s.z + bb.z, 0.f); s.w = fmaxf(s.w + bb.w, 0.f);
+  reinterpret_cast<float4*>(hid)[(long)b * 256 + t] = s;
+  float acc[FLM_DQN_MAX_ACTIONS];
+#pragma unroll
+  for (int a = 0; a < FLM_DQN_MAX_ACTIONS; a++) acc[a] = 0.f;
+  if (adv) {
+#pragma unroll
+    for (int a = 0; a < FLM_DQN_MAX_ACTIONS; a++)
+      if (a < NA) {
+        const float* wr = a2w + a * 512 + u;
+        acc[a] = fmaf(s.w, wr[3], fmaf(s.z, wr[2], fmaf(s.y, wr[1], s.x * wr[0])));
+      }
+  } else {
+    const float* wr = v2w + u;
+    acc[0] = fmaf(s.w, wr[3], fmaf(s.z, wr[2], fmaf(s.y, wr[1], s.x * wr[0])));
+  }
+#pragma unroll
+  for (int a = 0; a < FLM_DQN_MAX_ACTIONS; a++)
+    if (a < NA || a == 0) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc[a] += __shfl_xor(acc[a], o);
+      if (lane == 0) red[w][a] = acc[a];
+    }
+  __syncthreads();
+  if (t == 0) {
+    const float val = (red[2][0] + red[3][0]) + v2b[0];
+    float av[FLM_DQN_MAX_ACTIONS], sum = 0.f;
+#pragma unroll
+    for (int a = 0; a < FLM_DQN_MAX_ACTIONS; a++)
+      if (a < NA) {
+        av[a] = (red[0][a] + red[1][a]) + a2b[a];
+        sum += av[a];
+      }
+    const float mean = NA == 2 ? sum * 0.5f : sum / (float)NA;
+#pragma unroll
+    for (int a = 0; a < FLM_DQN_MAX_ACTIONS; a++)
+      if (a < NA) q[b * NA + a] = val + av[a] - mean;
+  }
+}
+
 // Double-DQN target and loss gradient (src/agent.py:97-111):
 //   a* = argmax_a q_next_local[b,a];  target = r + gamma * q_next_target[b,a*] * (1 - done)
 //   loss = mean_b (q[b,action[b]] - target)^2;  dq[b,a] = 2*(q - target)/B on the taken action, else 0
@@ -1172,15 +1244,20 @@ extern "C" long flm_dqn_forward_workspace(int B, int H3) {
   return (long)B * 64 * H3 + (long)B * 1024 + (long)fc1_k_slices(B) * B * 1024;
 }
 
-// x: float input [B,H3,T1], or nullptr when the input is obs_u8 [B,3,plane_stride] (H3 = 3*Rp)
-static int dqn_forward_impl(const float* params, const float* x, const uint8_t* obs_u8, int plane_stride, int B, int H3,
-                            int T1, int NA, float* x1, float* hid, float* part, float* q, hipStream_t stream) {
+// small batches (act): the first dense layer streams both weight matrices in one launch
+static bool dqn_rows_path(const float* params, const DqnLayout& L, int B, const float* x1) {
+  return B <= 8 && (L.K1 & 3) == 0 &&
+         (((uintptr_t)(params + L.a1_w) | (uintptr_t)(params + L.v1_w) | (uintptr_t)x1) & 15) == 0;
+}
+
+// The convolution: x1[B,64,H3] from x, the float input [B,H3,T1], or (x == nullptr) from obs_u8 [B,3,plane_stride]
+// with H3 = 3*Rp.
+static int dqn_conv_stage(const float* params, const float* x, const uint8_t* obs_u8, int plane_stride, int B, int H3,
+                          int T1, int NA, float* x1, hipStream_t stream) {
   DqnLayout L(H3, T1, NA);
   GemmArgs g{};
   int rc;
-  // small batches (act): the first dense layer streams both weight matrices in one launch
-  const bool rows_path = B <= 8 && (L.K1 & 3) == 0 &&
-                         (((uintptr_t)(params + L.a1_w) | (uintptr_t)(params + L.v1_w) | (uintptr_t)x1) & 15) == 0;
+  const bool rows_path = dqn_rows_path(params, L, B, x1);
   const size_t conv_rows_lds = sizeof(float) * ((size_t)T1 * 65 + 4 * (size_t)T1);
   if (x && rows_path && conv_rows_lds <= 64 * 1024) {
     const long M = (long)B * H3;
@@ -1218,6 +1295,17 @@ static int dqn_forward_impl(const float* params, const float* x, const uint8_t* 
       rc = FLM_E_ARG;
     if (rc) return rc;
   }
+  return FLM_OK;
+}
+
+// The dense layers behind the convolution: hid[B,1024] and q[B,NA] from x1[B,64*H3]; part is workspace for the K
+// slices of the first dense layer (fc1_k_slices(B) * B * 1024 floats).
+static int dqn_dense_stage(const float* params, int B, int H3, int T1, int NA, const float* x1, float* hid, float* part,
+                           float* q, hipStream_t stream) {
+  DqnLayout L(H3, T1, NA);
+  GemmArgs g{};
+  int rc;
+  const bool rows_path = dqn_rows_path(params, L, B, x1);
   if (rows_path) {
     if (B == 1)
       hipLaunchKernelGGL(flm::fc1_rows_kernel<1>, dim3(256), dim3(1024), 0, stream, x1, params + L.a1_w, params + L.v1_w,
@@ -1246,6 +1334,14 @@ static int dqn_forward_impl(const float* params, const float* x, const uint8_t* 
     g.a_zs = 0; g.b_zs = L.v1_w - L.a1_w; g.c_zs = (long)B * 1024; g.c_gs = 512; g.groups = 2; g.ksplit = ks;
     rc = flm::launch_gemm<true, true, flm::EPI_PLAIN>(g, 2 * nks, stream);
     if (rc) return rc;
+    // the reduction over the K slices with bias and ReLU, and the output layers behind it, in one launch where the
+    // buffers allow 16-byte accesses
+    if ((((uintptr_t)part | (uintptr_t)hid | (uintptr_t)(params + L.a1_b) | (uintptr_t)(params + L.v1_b)) & 15) == 0) {
+      hipLaunchKernelGGL(flm::fc1_reduce_head_kernel, dim3(B), dim3(256), 0, stream, part, nks, B, params + L.a1_b,
+                         params + L.v1_b, hid, params + L.a2_w, params + L.a2_b, params + L.v2_w, params + L.v2_b, NA, q);
+      if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
+      return FLM_OK;
+    }
     const long ne = (long)B * 1024;
     hipLaunchKernelGGL(flm::reduce_bias_relu_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream, part, nks, B,
                        1024, params + L.a1_b, params + L.v1_b, 512, hid, 1024L);
@@ -1254,6 +1350,12 @@ static int dqn_forward_impl(const float* params, const float* x, const uint8_t* 
                      params + L.v2_w, params + L.v2_b, B, NA, q);
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
+}
+
+static int dqn_forward_impl(const float* params, const float* x, const uint8_t* obs_u8, int plane_stride, int B, int H3,
+                            int T1, int NA, float* x1, float* hid, float* part, float* q, hipStream_t stream) {
+  const int rc = dqn_conv_stage(params, x, obs_u8, plane_stride, B, H3, T1, NA, x1, stream);
+  return rc ? rc : dqn_dense_stage(params, B, H3, T1, NA, x1, hid, part, q, stream);
 }
 
 extern "C" int flm_dqn_forward(const float* params, const float* x, int B, int H3, int T1, int NA, float* workspace,
@@ -1288,6 +1390,12 @@ extern "C" int flm_obs_to_f32(const uint8_t* obs, int n, int Rp, int T1, int pla
   return FLM_OK;
 }
 
+// split-K partials of a learn step: the local network's two forward passes run as one batch of 2B
+static long learn_part_floats(int B) {
+  const long one = (long)fc1_k_slices(B) * B * 1024, two = (long)fc1_k_slices(2 * B) * 2 * B * 1024;
+  return one > two ? one : two;
+}
+
 // workspace floats needed by flm_dqn_learn_grads
 extern "C" long flm_dqn_learn_workspace(int B, int H3, int T1, int NA) {
   if (!actions_ok(NA)) return 0;
@@ -1296,7 +1404,7 @@ extern "C" long flm_dqn_learn_workspace(int B, int H3, int T1, int NA) {
          + (long)B * 1024                                     // dhid
          + (long)B * 64 * H3                                  // dx1
          + (long)B * 64 * T1                                  // per-sample conv weight partials
-         + (long)fc1_k_slices(B) * B * 1024                   // split-K partials of the first dense layer
+         + learn_part_floats(B)                               // split-K partials of the first dense layer
          + (((5L * NA + 2) * B + 64 + 3) & ~3L);              // three q's, dq, dadv; dval, squared errors (whole 16 bytes)
 }
 
@@ -1312,15 +1420,16 @@ extern "C" long flm_dqn_learn_workspace(int B, int H3, int T1, int NA) {
 struct LearnWorkspace {
   float *x1, *hid, *x1n, *hidn, *x1t, *hidt, *dhid, *dx1, *cpart, *part, *q, *qn, *qt, *dq, *dadv, *dval, *sq;
   LearnWorkspace(float* ws, int B, int H3, int T1, int NA) {
+    // x1 / x1n, hid / hidn and q / qn are adjacent: the local network sees [s; s'] as one batch of 2B
     const long n_x1 = (long)B * 64 * H3, n_hid = (long)B * 1024;
-    x1 = ws;             hid = x1 + n_x1;
-    x1n = hid + n_hid;   hidn = x1n + n_x1;
+    x1 = ws;             x1n = x1 + n_x1;
+    hid = x1n + n_x1;    hidn = hid + n_hid;
     x1t = hidn + n_hid;  hidt = x1t + n_x1;
     dhid = hidt + n_hid;
     dx1 = dhid + n_hid;
     cpart = dx1 + n_x1;
     part = cpart + (long)B * 64 * T1;
-    q = part + (long)fc1_k_slices(B) * B * 1024;
+    q = part + learn_part_floats(B);
     qn = q + (long)NA * B; qt = qn + (long)NA * B; dq = qt + (long)NA * B;
     dadv = dq + (long)NA * B; dval = dadv + (long)NA * B; sq = dval + B;
   }
@@ -1338,12 +1447,13 @@ static int learn_dense_half(const float* local, const float* target, const float
                        H3 / 3, T1, plane_stride, const_cast<float*>(s));
     if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   }
-  if ((rc = dqn_forward_impl(local, s_u8 ? nullptr : s, s_u8, plane_stride, B, H3, T1, NA, w.x1, w.hid, w.part, w.q, stream)))
+  // The local network on the states and, under double DQN (where its view of the next states picks the action), on
+  // the next states as well: two convolutions into adjacent halves, then the dense layers once over 2B samples (the
+  // weights of the first dense layer are read once, and its K slices are half as many).
+  if ((rc = dqn_conv_stage(local, s_u8 ? nullptr : s, s_u8, plane_stride, B, H3, T1, NA, w.x1, stream))) return rc;
+  if (double_dqn && (rc = dqn_conv_stage(local, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, NA, w.x1n, stream)))
     return rc;
-  // the local network's view of the next states picks the action only under double DQN
-  if (double_dqn && (rc = dqn_forward_impl(local, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, NA, w.x1n, w.hidn,
-                                           w.part, w.qn, stream)))
-    return rc;
+  if ((rc = dqn_dense_stage(local, double_dqn ? 2 * B : B, H3, T1, NA, w.x1, w.hid, w.part, w.q, stream))) return rc;
   if ((rc = dqn_forward_impl(target, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, NA, w.x1t, w.hidt, w.part, w.qt,
                              stream)))
     return rc;
