@@ -7,6 +7,7 @@ under a fixed seed, which the tests reproduce with the same torch version.
 """
 import argparse
 import collections
+import copy
 import collections.abc
 import os
 import sys
@@ -114,8 +115,60 @@ def main_plain():
         print(k, v.shape, v.ravel()[:4])
 
 
+def main_trained():
+    """Q-values of the reference's network after training has moved its weights -> dqn_reference_trained.npz.
+    The reference's own DQNAgent runs 30 learn steps (lr 1e-3) on a fixed batch; the resulting weights are rounded to
+    float16 so that they can be stored (2.7 MB) and loaded bit for bit on both sides, loaded back into the reference's
+    Dueling_DQN, and its Q-values for 64 real observations are recorded in float32 and float64.  The network is the
+    real architecture at max_rails = 7 (observations of bundled maps cropped to their first seven rails per plane):
+    the weights of the full-size network would be 39 MB even as float16."""
+    from tests import dqn_inputs as di
+    Rp, T1 = di.TRAINED_RAILS, di.DEPTH + 1
+    H3 = 3 * Rp
+    B = 16
+    args = argparse.Namespace(prediction_depth=di.DEPTH, lr=1e-3, buffer_size=100, batch_size=B, update_every=10, gamma=0.99,
+                              tau=1e-3)
+    torch.manual_seed(99)
+    agent = DQNAgent(args, action_space=2, bitmap_height=H3)
+    init = [p.detach().clone() for p in agent.qnetwork_local.parameters()]
+    s, a, r, sn, d = di.trained_learn_batch(B)
+    exp = (torch.from_numpy(s)[:, None], torch.from_numpy(a), torch.from_numpy(r), torch.from_numpy(sn)[:, None],
+           torch.from_numpy(d.astype(np.uint8)).float())
+    import torch.nn.functional as F
+    real, losses = F.mse_loss, []
+
+    def spy(x, y, *aa, **kw):
+        v = real(x, y, *aa, **kw)
+        losses.append(float(v))
+        return v
+    F.mse_loss = spy
+    for _ in range(30):
+        agent.learn(exp, args.gamma)
+    F.mse_loss = real
+    out = {"losses": np.array(losses)}
+    moved = [float((p.detach() - p0).abs().max()) for p, p0 in zip(agent.qnetwork_local.parameters(), init)]
+    out["moved_max"] = np.array(moved)
+    # the stored weights: float16 roundings of the trained ones
+    half = [p.detach().to(torch.float16) for p in agent.qnetwork_local.parameters()]
+    for i, h in enumerate(half):
+        out["w%d" % i] = h.numpy().view(np.uint16)
+    net = Dueling_DQN(T1, H3, 2)
+    with torch.no_grad():
+        for p, h in zip(net.parameters(), half):
+            p.copy_(h.float())
+    x = torch.from_numpy(di.trained_observations(64))[:, None]
+    with torch.no_grad():
+        out["q32"] = net(x).numpy()
+        out["q64"] = copy.deepcopy(net).double()(x.double()).numpy()
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "dqn_reference_trained.npz"), **out)
+    print("losses", losses[0], losses[-1], "moved", moved, "q", out["q64"][:3], "bytes",
+          os.path.getsize(os.path.join(ROOT, "tests", "golden", "dqn_reference_trained.npz")))
+
+
 if __name__ == "__main__":
-    if "plain" in sys.argv[1:]:
+    if "trained" in sys.argv[1:]:
+        main_trained()
+    elif "plain" in sys.argv[1:]:
         main_plain()
     else:
         main()
