@@ -47,7 +47,7 @@ _SIGNATURES = {
     "flm_rollout_classify": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "flm_rollout_apply": [_p] * 18 + [_i] * 6 + [_p, _p, _p, _p],
     "flm_env_step": [_p] * 13 + [_i] * 4 + [_p] * 6 + [_u32, _i, _i, _i, _p],
-    "flm_altpaths": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
+    "flm_altpaths": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     "flm_check_crash": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     "flm_update_bitmaps": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "flm_dqn_param_count": [_i, _i, _i],

@@ -419,7 +419,7 @@ class ObservationBatch:
             meta=torch.empty((n, cap_alt, Lcap), dtype=torch.int32, device=dev),
             err=torch.empty((n,), dtype=torch.int32, device=dev), req=req, Lcap=Lcap, cap_alt=cap_alt)
         call("flm_altpaths", ptr(self.grid), ptr(self.cell_idx), ptr(self.dist), ptr(self.succ_table()),
-             ptr(self.choice_table()), ptr(self.tslot), ptr(self.node_id),
+             ptr(self.choice_table()), ptr(self.idx_cell), ptr(self.tslot), ptr(self.node_id),
              ptr(req), n, ptr(self.pos_cell), ptr(self.direction), ptr(self.target_cell), self.E, self.A, self.H,
              self.W, self.cap_cells, int(max_depth), cap_alt, Lcap, ptr(out["count"]), ptr(out["len"]),
              ptr(out["cell"]), ptr(out["meta"]), ptr(out["err"]), self.stream.cuda_stream)

@@ -172,6 +172,10 @@ __device__ __forceinline__ int block_int_scan(int v, int* scratch, int* total) {
 // (0xFFFF = no such move) and a flag "the move is reported as forward" (a single exit, or the U-turn of a
 // dead end, which sits in the forward slot).  With it a step with a choice reads one table entry and the
 // candidates' distances instead of the cell code and the state numbers of the neighbouring cells.
+// WIDE: elements are collected four at a time and leave as 16-byte stores (many walks side by side: fewer store
+// instructions); otherwise every element is stored as it is found (one walk alone: the shortest dependent chain per
+// step).  The tables may live in LDS or in global memory.
+template <bool WIDE = true>
 __device__ __forceinline__ int greedy_path(const uint16_t* __restrict__ grid, const int32_t* __restrict__ cell_idx,
                                            const uint16_t* __restrict__ dist, const uint16_t* __restrict__ succ,
                                            const uint16_t* __restrict__ choice, int H, int W, int cell, int h, int tcell,
@@ -181,7 +185,7 @@ __device__ __forceinline__ int greedy_path(const uint16_t* __restrict__ grid, co
   int s = -1;                 // compact state number of (cell, h) while it is known
   bool reach = false;         // the current state is known to reach the target, best_d is its distance
   // elements are collected four at a time and stored as 16 bytes when the output rows are 16-byte aligned
-  const bool vec = ((reinterpret_cast<size_t>(pc) | reinterpret_cast<size_t>(pm)) & 15) == 0;
+  const bool vec = WIDE && ((reinterpret_cast<size_t>(pc) | reinterpret_cast<size_t>(pm)) & 15) == 0;
   int bc[4] = {0, 0, 0, 0};
   unsigned bm[4] = {0, 0, 0, 0};
   auto emit = [&](int c, unsigned m) {
@@ -219,13 +223,20 @@ __device__ __forceinline__ int greedy_path(const uint16_t* __restrict__ grid, co
           best_d = d0;
           reach = true;
         }
-        const int nd = (int)(nx & 3u);
-        emit(cell, (unsigned)h | (2u << 8) | ((unsigned)nd << 16));
-        depth++;
-        cell += dr(nd) * W + dc(nd);
-        h = nd;
-        s = (int)nx;
-        best_d -= 1;
+        // the whole forced run: no state of it lies on a target cell (such states have no forced successor), so
+        // the walk cannot arrive inside it; only the horizon can end it early
+        unsigned nxt = nx;
+        do {
+          const int nd = (int)(nxt & 3u);
+          emit(cell, (unsigned)h | (2u << 8) | ((unsigned)nd << 16));
+          depth++;
+          cell += dr(nd) * W + dc(nd);
+          h = nd;
+          s = (int)nxt;
+          best_d -= 1;
+          if (depth >= max_depth) break;
+          nxt = succ[s];
+        } while (nxt != 0xFFFFu);
         continue;
       }
     }

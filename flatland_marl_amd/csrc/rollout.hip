@@ -11,9 +11,11 @@ namespace flm {
 // leaf; then every lane completes one leaf by a greedy descent of at most max_depth moves, so the walks of
 // a request run side by side; last, leaves whose descent found no way are squeezed out in order.
 // More than cap_alt leaves is FLM_AGENT_OVERFLOW.
-// STAGE: one request per wave (G = 64) and the environment's successor table (2 bytes per state) copied into LDS
-// first, so that the forced steps of the descents - most of a path, one dependent look-up each - run at LDS
-// latency; the kernel is bound by the latency of one descent, not by throughput.
+// STAGE: one request per wave (G = 64) and the tables a descent reads copied into LDS first: the environment's
+// successor table (2 bytes per state) and choice table (8 bytes per state) and the distance row of the request's
+// target (2 bytes per state).  The kernel is bound by the latency of its longest descent, a chain of dependent
+// look-ups: forced steps take one look-up each, steps with a choice two (the choice entry, then the candidates'
+// distances), and from LDS both kinds run at LDS latency instead of a round trip to memory.
 #define FLM_ALT_STACK 32
 #define FLM_ALT_FRAME_INTS (2 * (FLM_ALT_STACK + 2) + 4 * FLM_ALT_STACK + 6 * FLM_ALT_STACK)   // per request
 
@@ -21,13 +23,13 @@ template <bool STAGE>
 __global__ __launch_bounds__(64) void altpaths_kernel(
     const uint16_t* __restrict__ grid_all, const int32_t* __restrict__ cell_idx_all,
     const uint16_t* __restrict__ dist_all, const uint16_t* __restrict__ succ_all,
-    const uint16_t* __restrict__ choice_all, const int32_t* __restrict__ tslot,
+    const uint16_t* __restrict__ choice_all, const int32_t* __restrict__ idx_cell_all, const int32_t* __restrict__ tslot,
     const int32_t* __restrict__ node_id_all, const int32_t* __restrict__ req_agent, int n_req,
     const int32_t* __restrict__ pos_cell, const int32_t* __restrict__ direction,
     const int32_t* __restrict__ target_cell, int A, int H, int W, int capCells, int max_depth, int cap_alt, int Lcap,
     int G, int32_t* __restrict__ alt_count, int32_t* __restrict__ alt_len, int32_t* __restrict__ alt_cell,
     uint32_t* __restrict__ alt_meta, int32_t* __restrict__ err_out) {
-  __shared__ int s_cell[64], s_h[64], s_base[64], s_res[64], s_n[64], s_err[64];
+  __shared__ int s_cell[64], s_h[64], s_base[64], s_res[64], s_n[64], s_err[64], s_cnt[64];
   extern __shared__ __attribute__((aligned(16))) int alt_frames[];     // [64 / G][FLM_ALT_FRAME_INTS], then the staged table
   const int lane = threadIdx.x, grp = lane / G, j = lane - grp * G;
   const int g = blockIdx.x * (64 / G) + grp;
@@ -41,13 +43,29 @@ __global__ __launch_bounds__(64) void altpaths_kernel(
   const uint16_t* dist = dist_all + ((size_t)e * A + tslot[ga]) * capCells * 4;
   const uint16_t* succ = succ_all ? succ_all + (size_t)e * capCells * 4 : nullptr;
   const uint16_t* choice = succ_all && choice_all ? choice_all + (size_t)e * capCells * 16 : nullptr;
-  uint16_t* succ_lds = reinterpret_cast<uint16_t*>(alt_frames + FLM_ALT_FRAME_INTS);   // STAGE: [capCells * 4]
+  // STAGE: [capCells * 16] choice, [capCells * 4] successors, [capCells * 4] distances (16 bits each), [capCells] grid
+  // cell of every rail cell, [cap_alt][Lcap] the descents' records (capCells is even: every table is a whole number of
+  // 16-byte pieces)
+  uint16_t* choice_lds = reinterpret_cast<uint16_t*>(alt_frames + FLM_ALT_FRAME_INTS);
+  uint16_t* succ_lds = choice_lds + (size_t)capCells * 16;
+  uint16_t* dist_lds = succ_lds + (size_t)capCells * 4;
+  int32_t* icell_lds = reinterpret_cast<int32_t*>(dist_lds + (size_t)capCells * 4);
+  uint32_t* rec_lds = reinterpret_cast<uint32_t*>(icell_lds + capCells);
   if (STAGE) {
-    // (G = 64: the whole wave serves one request, e is the same for every lane)
-    const uint4* src = reinterpret_cast<const uint4*>(succ);
-    uint4* dst = reinterpret_cast<uint4*>(succ_lds);
-    for (int i = lane; i < capCells / 2; i += 64) dst[i] = src[i];     // capCells * 8 bytes, 16 per copy
-    if ((capCells & 1) && lane < 4) succ_lds[(capCells - 1) * 4 + lane] = succ[(capCells - 1) * 4 + lane];
+    // (G = 64: the whole wave serves one request, e and the target are the same for every lane)
+    const uint4* src_c = reinterpret_cast<const uint4*>(choice);
+    const uint4* src_s = reinterpret_cast<const uint4*>(succ);
+    const uint4* src_d = reinterpret_cast<const uint4*>(dist);
+    const int32_t* src_i = idx_cell_all + (size_t)e * capCells;
+    uint4* dst_c = reinterpret_cast<uint4*>(choice_lds);
+    uint4* dst_s = reinterpret_cast<uint4*>(succ_lds);
+    uint4* dst_d = reinterpret_cast<uint4*>(dist_lds);
+    for (int i = lane; i < capCells * 2; i += 64) dst_c[i] = src_c[i];   // capCells * 32 bytes, 16 per copy
+    for (int i = lane; i < capCells / 2; i += 64) {                      // capCells * 8 bytes each
+      dst_s[i] = src_s[i];
+      dst_d[i] = src_d[i];
+    }
+    for (int i = lane; i < capCells; i += 64) icell_lds[i] = src_i[i];
   }
   const int tcell = target_cell[ga];
   int32_t* out_len = alt_len + (size_t)g * cap_alt;
@@ -141,15 +159,96 @@ __global__ __launch_bounds__(64) void altpaths_kernel(
       if (start == -1) {
         res = base;
       } else if (start >= 0) {
-        const int n = greedy_path(grid, cell_idx, dist, STAGE ? succ_lds : succ, choice, H, W, start, s_h[lane], tcell,
-                                  max_depth, slot_cell + (size_t)j * Lcap + base, slot_meta + (size_t)j * Lcap + base,
-                                  Lcap - base);
+        int n;
+        if (STAGE) {
+          // The descent of greedy_path() on the staged tables, one dependent LDS look-up per forced step: an
+          // element is recorded as state | action << 16 | next heading << 20; cells and the output layout follow
+          // when all lanes copy the records out.
+          uint32_t* rec = rec_lds + (size_t)j * Lcap;
+          const int cap = Lcap - base;
+          const int tci = (tcell >= 0 && tcell < HW) ? cell_idx[tcell] : -1;
+          const int idx0 = cell_idx[start];
+          n = -1;
+          if (idx0 >= 0) {
+            int st = idx0 * 4 + s_h[lane], depth = 0;
+            unsigned best_d = 0xFFFFFFFFu;
+            bool reach = false, dead = false;
+            n = 0;
+            while ((st >> 2) != tci && depth < max_depth) {
+              unsigned nx = succ_lds[st];
+              if (nx != 0xFFFFu) {
+                if (!reach) {
+                  const unsigned d0 = dist_lds[st];
+                  if (d0 == FLM_DIST_INF) { dead = true; break; }
+                  best_d = d0;
+                  reach = true;
+                }
+                do {                       // a forced run never crosses a target cell: only the horizon ends it early
+                  if (n < cap) rec[n] = (unsigned)st | (2u << 16) | ((nx & 3u) << 20);
+                  n++;
+                  depth++;
+                  st = (int)nx;
+                  best_d -= 1;
+                  if (depth >= max_depth) break;
+                  nx = succ_lds[st];
+                } while (nx != 0xFFFFu);
+                continue;
+              }
+              const uint2 raw = *reinterpret_cast<const uint2*>(choice_lds + (size_t)st * 4);
+              const unsigned ns[3] = {raw.x & 0xFFFFu, raw.x >> 16, raw.y & 0xFFFFu};
+              int best = -1;
+              unsigned best_s = 0;
+#pragma unroll
+              for (int i = 0; i < 3; i++) {
+                if (ns[i] == 0xFFFFu) continue;
+                const unsigned dd = dist_lds[ns[i]];
+                if (dd != FLM_DIST_INF && dd < best_d) {
+                  best = i;
+                  best_d = dd;
+                  best_s = ns[i];
+                }
+              }
+              if (best < 0) { dead = true; break; }
+              const unsigned action = (raw.y >> 16) & 1u ? 2u : (unsigned)(1 + best);
+              if (n < cap) rec[n] = (unsigned)st | (action << 16) | ((best_s & 3u) << 20);
+              n++;
+              depth++;
+              st = (int)best_s;
+              reach = true;
+            }
+            if (dead) {
+              n = -1;
+            } else if (depth < max_depth) {     // closing element: stop on the cell reached
+              if (n < cap) rec[n] = (unsigned)st | (4u << 16) | (((unsigned)st & 3u) << 20);
+              n++;
+            }
+          }
+          s_cnt[lane] = n < 0 ? 0 : (n < cap ? n : cap);
+        } else {
+          n = greedy_path<true>(grid, cell_idx, dist, succ, choice, H, W, start, s_h[lane], tcell, max_depth,
+                                slot_cell + (size_t)j * Lcap + base, slot_meta + (size_t)j * Lcap + base, Lcap - base);
+        }
         if (n >= 0) res = base + n > Lcap ? -2 : base + n;
       }
       s_res[lane] = res;
     }
   }
   __syncthreads();
+  if (STAGE && live && !err) {
+    // the records of every descent become path elements: all lanes, coalesced
+    for (int q = 0; q < n_leaf; q++) {
+      if (s_cell[q] < 0) continue;        // no descent ran for this leaf
+      const int cnt = s_cnt[q], base = s_base[q];
+      const uint32_t* rec = rec_lds + (size_t)q * Lcap;
+      for (int i = lane; i < cnt; i += 64) {
+        const unsigned v = rec[i];
+        const unsigned st = v & 0xFFFFu;
+        slot_cell[(size_t)q * Lcap + base + i] = icell_lds[st >> 2];
+        slot_meta[(size_t)q * Lcap + base + i] = (st & 3u) | (((v >> 16) & 7u) << 8) | (((v >> 20) & 3u) << 16);
+      }
+    }
+    __syncthreads();                       // the squeeze below reads what other lanes have just written
+  }
   int n_alt = 0;
   if (live && !err) {
     for (int q = 0; q < n_leaf; q++) {
@@ -360,7 +459,8 @@ __global__ __launch_bounds__(256) void update_bitmaps_kernel(int8_t* __restrict_
 }  // namespace flm
 
 extern "C" int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const uint16_t* dist, const uint16_t* succ,
-                            const uint16_t* choice, const int32_t* tslot, const int32_t* node_id, const int32_t* req_agent, int n_req, const int32_t* pos_cell,
+                            const uint16_t* choice, const int32_t* idx_cell, const int32_t* tslot, const int32_t* node_id,
+                            const int32_t* req_agent, int n_req, const int32_t* pos_cell,
                             const int32_t* direction, const int32_t* target_cell, int E, int A, int H, int W,
                             int capCells, int max_depth, int cap_alt, int Lcap, int32_t* alt_count, int32_t* alt_len,
                             int32_t* alt_cell, uint32_t* alt_meta, int32_t* err, void* stream) {
@@ -372,13 +472,15 @@ extern "C" int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const
     return FLM_E_ARG;
   int G = 1;                              // lanes per request
   while (G < cap_alt) G *= 2;
-  // one request per wave with the successor table in LDS when there is one, it is 16-byte aligned per environment
-  // and it fits beside the frames
-  const size_t staged_lds = (size_t)FLM_ALT_FRAME_INTS * sizeof(int) + (size_t)capCells * 8 + 16;
-  const bool stage = succ && choice && (((uintptr_t)succ | ((size_t)capCells * 8)) & 15) == 0 && staged_lds <= 64 * 1024;
+  // one request per wave with the successor, choice, distance and cell tables and the descents' records in LDS when
+  // the tables exist, are 16-byte aligned per environment and target (an even capCells) and fit beside the frames
+  const size_t staged_lds = (size_t)FLM_ALT_FRAME_INTS * sizeof(int) + (size_t)capCells * 52 + (size_t)cap_alt * Lcap * 4 + 16;
+  const bool stage = succ && choice && idx_cell && (capCells & 1) == 0 && capCells * 4 <= 65535 &&
+                     (((uintptr_t)succ | (uintptr_t)choice | (uintptr_t)dist) & 15) == 0 && staged_lds <= 64 * 1024;
   if (stage) {
+    FLM_RAISE_LDS_ONCE(flm::altpaths_kernel<true>);
     hipLaunchKernelGGL(flm::altpaths_kernel<true>, dim3(n_req), dim3(64), staged_lds, (hipStream_t)stream, grid, cell_idx,
-                       dist, succ, choice, tslot, node_id, req_agent, n_req, pos_cell, direction, target_cell, A, H, W,
+                       dist, succ, choice, idx_cell, tslot, node_id, req_agent, n_req, pos_cell, direction, target_cell, A, H, W,
                        capCells, max_depth, cap_alt, Lcap, 64, alt_count, alt_len, alt_cell, alt_meta, err);
   } else {
     const int per_block = 64 / G;
@@ -386,7 +488,7 @@ extern "C" int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const
     if (lds > 160 * 1024 - 512) return FLM_E_ARG;
     FLM_RAISE_LDS_ONCE(flm::altpaths_kernel<false>);
     hipLaunchKernelGGL(flm::altpaths_kernel<false>, dim3((n_req + per_block - 1) / per_block), dim3(64), lds,
-                       (hipStream_t)stream, grid, cell_idx, dist, succ, choice, tslot, node_id, req_agent, n_req, pos_cell,
+                       (hipStream_t)stream, grid, cell_idx, dist, succ, choice, idx_cell, tslot, node_id, req_agent, n_req, pos_cell,
                        direction, target_cell, A, H, W, capCells, max_depth, cap_alt, Lcap, G, alt_count, alt_len, alt_cell,
                        alt_meta, err);
   }

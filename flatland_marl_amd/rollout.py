@@ -173,7 +173,7 @@ class RolloutBatch:
         for lo in range(0, n, MAX_REQ):
             hi = min(n, lo + MAX_REQ)
             call("flm_altpaths", ptr(b.grid), ptr(b.cell_idx), ptr(b.dist), ptr(b.succ_table()), ptr(b.choice_table()),
-                 ptr(b.tslot), ptr(b.node_id),
+                 ptr(b.idx_cell), ptr(b.tslot), ptr(b.node_id),
                  ptr(req[lo:hi]),
                  hi - lo, ptr(b.pos_cell), ptr(b.direction), ptr(b.target_cell), self.E, self.A, b.H, b.W, b.cap_cells,
                  self.max_alt_depth, K, self.Lp, ptr(alt["count"][lo:hi]), ptr(alt["len"][lo:hi]), ptr(alt["cell"][lo:hi]),

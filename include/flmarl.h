@@ -272,6 +272,10 @@ int flm_reorder_rails(const uint8_t* obs_in, uint8_t* obs_out, int n, int Rp, in
  * Replaces get_altpaths, src/utils/shortest_path.py:92-163 (called through
  * ShortestPathPredictorForRailEnv.get_altpaths, src/predictions.py:74-83, with max_depth = 500).
  *   req_agent [n_req] int32: e*A + a of each request; pos_cell/direction/target_cell [E,A] as above
+ *   succ, choice [E,capCells*4], [E,capCells*4,4] uint16: the forced-successor and choice tables of flm_chain_index
+ *   (or NULL: every step is then worked out from the grid); idx_cell [E,capCells] int32: the grid cell of every
+ *   rail cell (flm_state_index), or NULL; with all three and tables that fit the LDS a request's descents run on
+ *   staged copies
  *   alt_count [n_req] out; alt_len [n_req,cap_alt] out; alt_cell/alt_meta [n_req,cap_alt,Lcap] out in the
  *   path encoding of flm_shortest_paths; err [n_req] out (FLM_AGENT_ASSERT_ERROR where the reference's
  *   assertions at :108/:125 fail, FLM_AGENT_OVERFLOW when the branches before the first plain cells number
@@ -279,7 +283,8 @@ int flm_reorder_rails(const uint8_t* obs_in, uint8_t* obs_out, int n, int Rp, in
  *   cap_alt <= 64.
  * Alternatives come in the reference's order: moves left, forward, right, depth first. */
 int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const uint16_t* dist, const uint16_t* succ,
-                 const uint16_t* choice, const int32_t* tslot, const int32_t* node_id, const int32_t* req_agent, int n_req, const int32_t* pos_cell,
+                 const uint16_t* choice, const int32_t* idx_cell, const int32_t* tslot, const int32_t* node_id,
+                 const int32_t* req_agent, int n_req, const int32_t* pos_cell,
                  const int32_t* direction, const int32_t* target_cell, int E, int A, int H, int W, int capCells,
                  int max_depth, int cap_alt, int Lcap, int32_t* alt_count, int32_t* alt_len, int32_t* alt_cell,
                  uint32_t* alt_meta, int32_t* err, void* stream);
