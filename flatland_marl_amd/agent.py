@@ -116,7 +116,7 @@ class DQNAgent:
         r = rewards.to(dev, torch.float32).contiguous()
         d = dones.to(dev, torch.float32).contiguous()
         loss = torch.empty(1, dtype=torch.float32, device=dev)
-        self.optimizer.zero_grad()
+        self.optimizer._ensure()                            # (no zero_grad: the kernels write every gradient element)
         st = torch.cuda.current_stream(dev).cuda_stream
         args = (ptr(local), ptr(target), ptr(s), ptr(sn), ptr(a), ptr(r), ptr(d), float(gamma),
                 1 if self.double_dqn else 0, B, self.height, self.width, self.action_space, ptr(self._ws),
@@ -146,7 +146,7 @@ class DQNAgent:
         r = rewards.to(dev, torch.float32).contiguous()
         d = dones.to(dev, torch.float32).contiguous()
         loss = torch.empty(1, dtype=torch.float32, device=dev)
-        self.optimizer.zero_grad()
+        self.optimizer._ensure()                            # (no zero_grad: the kernels write every gradient element)
         st = torch.cuda.current_stream(dev).cuda_stream
         args = (ptr(local), ptr(target), ptr(s), ptr(sn), int(plane_stride), ptr(a), ptr(r), ptr(d),
                 float(gamma), 1 if self.double_dqn else 0, B, Rp, self.width, self.action_space, ptr(self._ws),

@@ -945,7 +945,6 @@ static unsigned obs_to_f32_pieces(int Rp, int T1) {
 // instructions of 64.  The filter bank is staged split as [term][filter][k] with k contiguous (a lane's operand is
 // one 16-byte read; rows an odd number of 16-byte slots apart), a lane's eight bytes of an observation row are
 // cut out of three aligned words (the row keeps its byte offset) and turned into bf16 in registers.
-#define CV_TILE 64
 #define CV_KP16(T1) (((T1) + 15) & ~15)                         // K padded to whole bf16 instructions
 #define CV_BROW(T1) (2 * CV_KP16(T1) + 16)                      // bytes per filter and term in LDS
 #define CV_ASTRIDE(T1) ((((T1) + 6) / 4 * 4) | 4)              // bytes per row in LDS: covers 3 + T1 bytes, word count odd
@@ -968,11 +967,15 @@ __device__ __forceinline__ uint2 bytes_to_bf16(unsigned w, int mode, bool sg) {
   return make_uint2(pack_hi16(__float_as_uint(f[0]), __float_as_uint(f[1])), pack_hi16(__float_as_uint(f[2]), __float_as_uint(f[3])));
 }
 
-template <int WPL, int NWAVE, bool BF>   // words a lane fetches per row (rows of up to 64*WPL words); waves per workgroup
+// WPL: words a lane fetches per row (rows of up to 64*WPL words); NWAVE: waves per workgroup; JT: tiles of 32 rows a
+// wave works on at a time (2: 64 rows share every filter fragment read; 1: half the rows per wave in LDS, so that
+// twice the waves fit a CU and hide one another's memory latency)
+template <int WPL, int NWAVE, bool BF, int JT>
 __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void conv_u8_kernel(
     const uint8_t* __restrict__ obs, const float* __restrict__ Wc, const float* __restrict__ bias, long M, int Rp, int T1,
     int H3, int plane_stride, long obs_bytes, float* __restrict__ x1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cv_lds[];
+  constexpr int CV_TILE = 32 * JT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int astr = CV_ASTRIDE(T1);
@@ -1097,43 +1100,44 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void conv_u8_kernel(
     if (t + GW < NT) prefetch(t + GW);
   }
   for (; t < NT; t += GW) {
-    const int os0 = __shfl(cur_os, c32), os1 = __shfl(cur_os, c32 + 32);
-    // sign extension from bit 7 for the signed plane, from bit 8 (never set) for the others
-    const unsigned wd0 = os0 & 4 ? 8u : 9u, wd1 = os1 & 4 ? 8u : 9u;
-    const unsigned char* b0p = Ab + c32 * astr + kh + (os0 & 3);
-    const unsigned char* b1p = Ab + (c32 + 32) * astr + kh + (os1 & 3);
+    int os[JT];                              // of the lane's row in every row tile: byte offset | 4 if signed
+#pragma unroll
+    for (int j = 0; j < JT; j++) os[j] = __shfl(cur_os, c32 + 32 * j);
     // the accumulators start from the bias of their filter (32 look-ups per tile instead of one per stored value)
-    f32x16 acc[2][2];
+    f32x16 acc[2][JT];
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const float bv = bl[32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh];
-        acc[i][0][r] = bv;
-        acc[i][1][r] = bv;
+#pragma unroll
+        for (int j = 0; j < JT; j++) acc[i][j][r] = bv;
       }
     if (BF) {
       // per row tile: the lane's row, the byte offset of the row inside its first word, and whether all / none /
       // some of the tile's rows are signed (wave-uniform)
-      const unsigned char* rp[2] = {Ab + c32 * astr + 8 * kh, Ab + (c32 + 32) * astr + 8 * kh};
-      const unsigned sh[2] = {(unsigned)os0 & 3u, (unsigned)os1 & 3u};
-      const bool sg[2] = {(os0 & 4) != 0, (os1 & 4) != 0};
-      int mode[2];
+      const unsigned char* rp[JT];
+      unsigned sh[JT];
+      bool sg[JT];
+      int mode[JT];
 #pragma unroll
-      for (int j = 0; j < 2; j++) {
+      for (int j = 0; j < JT; j++) {
+        rp[j] = Ab + (c32 + 32 * j) * astr + 8 * kh;
+        sh[j] = (unsigned)os[j] & 3u;
+        sg[j] = (os[j] & 4) != 0;
         const unsigned long long bs = __ballot(sg[j]);
         mode[j] = bs == 0ull ? 0 : bs == ~0ull ? 1 : 2;
       }
       const unsigned char* ap = bank + (size_t)c32 * brow + 16 * kh;
       for (int st = 0; st < KP16; st += 16) {
-        bf16x8 fa[2][3], fb[2];
+        bf16x8 fa[2][3], fb[JT];
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
           for (int t = 0; t < 3; t++)
             fa[i][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + ((size_t)t * 64 + 32 * i) * brow + 2 * st));
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < JT; j++) {
           const unsigned* wp3 = reinterpret_cast<const unsigned*>(rp[j] + st);
           const unsigned w0 = wp3[0], w1 = wp3[1], w2 = wp3[2];
           const unsigned lo = __builtin_amdgcn_alignbyte(w1, w0, sh[j]), hi = __builtin_amdgcn_alignbyte(w2, w1, sh[j]);
@@ -1143,7 +1147,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void conv_u8_kernel(
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
-          for (int j = 0; j < 2; j++) {
+          for (int j = 0; j < JT; j++) {
             f32x16 c = acc[i][j];
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j], c, 0, 0, 0);
@@ -1152,15 +1156,23 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void conv_u8_kernel(
           }
       }
     } else {
+    // sign extension from bit 7 for the signed plane, from bit 8 (never set) for the others
+    unsigned wd[JT];
+    const unsigned char* bp[JT];
+#pragma unroll
+    for (int j = 0; j < JT; j++) {
+      wd[j] = os[j] & 4 ? 8u : 9u;
+      bp[j] = Ab + (c32 + 32 * j) * astr + kh + (os[j] & 3);
+    }
     auto kstep = [&](int kk) {
-      const unsigned u0 = b0p[kk], u1 = b1p[kk];
       const float f0 = wp[kk * CV_WSTRIDE], f1 = wp[kk * CV_WSTRIDE + 32];
-      const float x0 = (float)(int)__builtin_amdgcn_sbfe((int)u0, 0u, wd0);
-      const float x1v = (float)(int)__builtin_amdgcn_sbfe((int)u1, 0u, wd1);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0, x0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0, x1v, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f1, x0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f1, x1v, acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < JT; j++) {
+        const unsigned u = bp[j][kk];
+        const float x = (float)(int)__builtin_amdgcn_sbfe((int)u, 0u, wd[j]);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0, x, acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f1, x, acc[1][j], 0, 0, 0);
+      }
     };
     int kk = 0;
     for (; kk + 8 <= KP; kk += 8) {
@@ -1181,7 +1193,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void conv_u8_kernel(
     }
     // acc[i][j][r]: filter 32*i + (r&3) + 8*(r>>2) + 4*kh of observation row 32*j + c32
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < JT; j++) {
       const unsigned d = __shfl(d_lane, c32 + 32 * j) + 4u * kh * uH3;
       if ((unsigned)(c32 + 32 * j) < o_rows) {
 #pragma unroll
@@ -1196,25 +1208,26 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void conv_u8_kernel(
   }
 }
 
-static size_t conv_u8_lds(int T1, int nwave, bool bf) {
-  const size_t rows = ((size_t)nwave * CV_TILE * CV_ASTRIDE(T1) + 15) & ~(size_t)15;
+static size_t conv_u8_lds(int T1, int nwave, bool bf, int tile_rows = 64) {
+  const size_t rows = ((size_t)nwave * tile_rows * CV_ASTRIDE(T1) + 15) & ~(size_t)15;
   // BF: 16 spare bytes behind the bias: the last row's third word may lie behind the rows of the last wave
   return bf ? rows + (size_t)3 * 64 * CV_BROW(T1) + 64 * 4 + 16 : rows + ((size_t)((T1 + 1) & ~1) * CV_WSTRIDE + 64) * 4;
 }
 
-template <int WPL, int NWAVE, bool BF>
+template <int WPL, int NWAVE, bool BF, int JT = 2>
 static int launch_conv_u8(const uint8_t* obs_u8, const float* Wc, const float* bias, long M, int Rp, int T1, int H3,
                           int plane_stride, long obs_bytes, float* x1, hipStream_t stream) {
-  const size_t lds = conv_u8_lds(T1, NWAVE, BF);
+  constexpr int CV_TILE = 32 * JT;
+  const size_t lds = conv_u8_lds(T1, NWAVE, BF, CV_TILE);
   if (lds > 160 * 1024 - 512) return FLM_E_ARG;
-  FLM_RAISE_LDS_ONCE((conv_u8_kernel<WPL, NWAVE, BF>));
+  FLM_RAISE_LDS_ONCE((conv_u8_kernel<WPL, NWAVE, BF, JT>));
   // persistent workgroups: one per CU (256 CUs)
   const long tiles = (M + CV_TILE - 1) / CV_TILE;
   long wgs = (tiles + NWAVE - 1) / NWAVE;
   if (wgs > 256) wgs = 256;
   if (wgs < 1) wgs = 1;
-  hipLaunchKernelGGL((conv_u8_kernel<WPL, NWAVE, BF>), dim3((unsigned)wgs), dim3(64 * NWAVE), lds, stream, obs_u8, Wc, bias, M,
-                     Rp, T1, H3, plane_stride, obs_bytes, x1);
+  hipLaunchKernelGGL((conv_u8_kernel<WPL, NWAVE, BF, JT>), dim3((unsigned)wgs), dim3(64 * NWAVE), lds, stream, obs_u8, Wc, bias,
+                     M, Rp, T1, H3, plane_stride, obs_bytes, x1);
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
 }
@@ -1279,9 +1292,12 @@ static int dqn_conv_stage(const float* params, const float* x, const uint8_t* ob
     const float* cw = params + L.conv_w;
     const float* cb = params + L.conv_b;
     const size_t cap = 160 * 1024 - 512;
-    // on the bf16 matrix cores while the split filter bank fits the LDS beside the rows of 8 or 4 waves; longer
-    // horizons on fp32 instructions
-    if (nword <= 64 && flm::conv_u8_lds(T1, 8, true) <= cap)
+    // on the bf16 matrix cores while the split filter bank fits the LDS beside the rows of the waves: sixteen waves
+    // with 32 rows each first (four per SIMD hide one another's memory latency), then 8 or 4 waves with 64 rows;
+    // longer horizons on fp32 instructions
+    if (nword <= 64 && flm::conv_u8_lds(T1, 16, true, 32) <= cap)
+      rc = flm::launch_conv_u8<1, 16, true, 1>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
+    else if (nword <= 64 && flm::conv_u8_lds(T1, 8, true) <= cap)
       rc = flm::launch_conv_u8<1, 8, true>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
     else if (nword <= 64 && flm::conv_u8_lds(T1, 4, true) <= cap)
       rc = flm::launch_conv_u8<1, 4, true>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);

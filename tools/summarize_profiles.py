@@ -67,6 +67,11 @@ json.dump({"workload": "cfg3 (bench.py --steps 2 --warmup 1), separate rocprofv3
                        "and TCC_EA0_RDREQ(+_32B); reads that are not 32-byte requests are priced at 128 bytes "
                        "(the doubling the guide prescribes for FETCH_SIZE on gfx950)", "kernels": tr},
           open(os.path.join(OUT, "%s_pmc_traffic.json" % tag), "w"), indent=1)
+# the figure bench.py reports as roofline.traffic: the sweep's bytes per launch, with the launch shape it was measured on
+for k, v in tr.items():
+    if "observations_columns_kernel" in k:
+        json.dump({"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "kernel": k, "source": "profiles/%s_pmc_traffic.json" % tag,
+                   "E": 4096, "A": 50, "plane_stride": 88320}, open(os.path.join(OUT, "obs_kernel_traffic_cfg3.json"), "w"))
 for k, v in tr.items():
     print("%-60s W %8.1f MB  R %8.1f MB" % (k[:60], v["write_bytes_per_launch"] / 1e6, v["read_bytes_per_launch"] / 1e6))
 for k, v in dq.items():
