@@ -1293,16 +1293,16 @@ static int dqn_conv_stage(const float* params, const float* x, const uint8_t* ob
     const float* cb = params + L.conv_b;
     const size_t cap = 160 * 1024 - 512;
     // on the bf16 matrix cores while the split filter bank fits the LDS beside the rows of the waves: sixteen waves
-    // with 32 rows each first (four per SIMD hide one another's memory latency), then 8 or 4 waves with 64 rows;
-    // longer horizons on fp32 instructions
+    // with 32 rows each first (four per SIMD hide one another's memory latency), then eight waves with 64 or 32
+    // rows, then four with 32 (depth 300: the bank alone is 120 KB); beyond that on fp32 instructions
     if (nword <= 64 && flm::conv_u8_lds(T1, 16, true, 32) <= cap)
       rc = flm::launch_conv_u8<1, 16, true, 1>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
     else if (nword <= 64 && flm::conv_u8_lds(T1, 8, true) <= cap)
       rc = flm::launch_conv_u8<1, 8, true>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
-    else if (nword <= 64 && flm::conv_u8_lds(T1, 4, true) <= cap)
-      rc = flm::launch_conv_u8<1, 4, true>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
-    else if (nword <= 128 && flm::conv_u8_lds(T1, 4, true) <= cap)
-      rc = flm::launch_conv_u8<2, 4, true>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
+    else if (nword <= 64 && flm::conv_u8_lds(T1, 8, true, 32) <= cap)       // (the LDS of four waves with 64 rows)
+      rc = flm::launch_conv_u8<1, 8, true, 1>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
+    else if (nword <= 128 && flm::conv_u8_lds(T1, 4, true, 32) <= cap)      // long horizons: the bank leaves room for four
+      rc = flm::launch_conv_u8<2, 4, true, 1>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
     else if (nword <= 64)
       rc = flm::launch_conv_u8<1, 4, false>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
     else if (nword <= 128)

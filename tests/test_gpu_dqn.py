@@ -328,7 +328,8 @@ def test_byte_planes_to_float_rows(n, Rp, T1, ps, off):
     assert np.all(got[n * 3 * Rp * T1:] == -7.0)          # nothing behind the last row is written
 
 
-@pytest.mark.parametrize("B,Rp,T1,pad", [(5, 10, 21, 0), (300, 7, 151, 3), (33, 4, 301, 1), (700, 100, 151, 0)])
+@pytest.mark.parametrize("B,Rp,T1,pad", [(5, 10, 21, 0), (300, 7, 151, 3), (33, 4, 301, 1), (700, 100, 151, 0),
+                                         (90, 6, 165, 2), (41, 9, 201, 1), (37, 5, 251, 0)])
 def test_forward_from_uint8_observations_vs_torch(B, Rp, T1, pad):
     """The byte-input forward (convolution reads int8 / uint8 planes) against plain PyTorch fp32 on the same values;
     plane strides that leave the rows at every byte alignment, horizons beyond 256 steps, ragged row tiles."""
