@@ -18,17 +18,16 @@ __device__ __forceinline__ bool on_rail(int c, int rail) { return c >= 0 && (c >
 __device__ __forceinline__ int col_dir(int c) { return c < 0 ? 0 : ((c & 1) ? 1 : -1); }
 __device__ __forceinline__ int col_enc(int rail, int dir) { return dir == 0 ? -1 : rail * 2 + (dir > 0 ? 1 : 0); }
 
-// np.argmax(row[from:] == 0) for the row `rail` of a plane given by its columns
-__device__ __forceinline__ int first_zero_col(const int16_t* row, int rail, int from, int T1) {
-  for (int t = from; t < T1; t++)
-    if (!on_rail(row[t], rail)) return t - from;
+// np.argmax(row[from:] == 0) for the row `rail` of a plane given by its columns, by the whole wave: 64 columns
+// per look, every lane returns the same value (the arguments are the same in every lane)
+__device__ __forceinline__ int wave_first_zero_col(const int16_t* row, int rail, int from, int T1) {
+  for (int base = from; base < T1; base += 64) {
+    const int t = base + (int)threadIdx.x;
+    const bool zero = t < T1 && !on_rail(row[t], rail);
+    const unsigned long long mk = __ballot(zero);
+    if (mk) return base + __ffsll(mk) - 1 - from;
+  }
   return 0;
-}
-
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-  return v;
 }
 
 struct ColEnv {
@@ -52,23 +51,36 @@ __device__ __forceinline__ int rail_dir(const ColEnv& m, int a, int ts, int* dir
 __device__ __forceinline__ int wave_last_train(const ColEnv& m, int a, int rail, int* last) {
   const int lane = threadIdx.x;
   int key = 0;
-  for (int o = lane; o < m.A; o += 64) {
-    if (o == a || m.status[o] == 0) continue;
-    const int16_t* row = m.row(o);
-    const int t = m.tpc[o];
-    int ex = -1;
-    if (on_rail(row[0], rail)) {
-      ex = first_zero_col(row, rail, 0, m.T1);
-    } else if (t >= 1 && t - 1 < m.T1 && on_rail(row[t - 1], rail)) {
-      const int c0 = row[0];
-      const int orail = c0 < 0 ? 0 : (c0 >> 1);
-      ex = 0;
-      if (orail != rail) ex = first_zero_col(row, orail, 0, m.T1);
-      ex += first_zero_col(row, rail, ex, m.T1);
+  for (int o0 = 0; o0 < m.A; o0 += 64) {
+    // one lane per train decides whether it is on the rail now (1) or when it leaves its current rail (2) ...
+    const int o = o0 + lane;
+    int kind = 0;
+    if (o < m.A && o != a && m.status[o] != 0) {
+      const int16_t* row = m.row(o);
+      const int t = m.tpc[o];
+      if (on_rail(row[0], rail)) kind = 1;
+      else if (t >= 1 && t - 1 < m.T1 && on_rail(row[t - 1], rail)) kind = 2;
     }
-    if (ex > 0) key = max(key, (ex << 12) | (4095 - o));
+    // ... and the wave scans the columns of the few trains that are
+    unsigned long long cand = __ballot(kind != 0);
+    while (cand) {
+      const int l = __ffsll(cand) - 1;
+      cand &= cand - 1;
+      const int oo = o0 + l;
+      const int16_t* row = m.row(oo);
+      int ex;
+      if (__shfl(kind, l) == 1) {
+        ex = wave_first_zero_col(row, rail, 0, m.T1);
+      } else {
+        const int c0 = row[0];
+        const int orail = c0 < 0 ? 0 : (c0 >> 1);
+        ex = 0;
+        if (orail != rail) ex = wave_first_zero_col(row, orail, 0, m.T1);
+        ex += wave_first_zero_col(row, rail, ex, m.T1);
+      }
+      if (ex > 0) key = max(key, (ex << 12) | (4095 - oo));
+    }
   }
-  key = wave_max(key);
   if (key == 0) {
     *last = 0;
     return 0;
@@ -158,7 +170,7 @@ __device__ __forceinline__ void wave_update_bitmaps(const ColEnv& m, int a, bool
     const int rail = rail_dir(m, a, t, &dir);
     const int le = wave_last_train(m, a, rail, &last);
     if (le > 0) {
-      const int cur = first_zero_col(row, rail, t, m.T1) + t;
+      const int cur = wave_first_zero_col(row, rail, t, m.T1) + t;
       if (cur <= le) wave_delay(m, a, rail, dir, le + t - cur);
     }
   }
@@ -175,14 +187,6 @@ __device__ __forceinline__ void wave_update_bitmaps(const ColEnv& m, int a, bool
     if (c < m.T1) row[c] = (int16_t)v[k];
   }
   __syncthreads();
-}
-
-__device__ __forceinline__ int path_next_cell(const int32_t* pc, const uint32_t* pm, int head, int len, int W) {
-  if (len < 0 || head >= len) return -1;
-  const int cell = pc[head];
-  const unsigned meta = pm[head];
-  const int act = (meta >> 8) & 0xFF, nh = (meta >> 16) & 3;
-  return act == 4 ? cell : cell + dr(nh) * W + dc(nh);
 }
 
 // Which of the five cases of the training loop (src/main.py:146-249) each agent is in this step:
@@ -233,7 +237,12 @@ __global__ void rollout_classify_kernel(const int32_t* __restrict__ status, cons
 // The per-agent part of one training-loop step (src/main.py:146-249) for every environment: one wave per
 // environment, agents in handle order.  net_in is the stop/go decision (1 = go) of the agents in cases 1
 // and 2; alt_slot/best pick the alternative a case-2 agent commits to.
-template <bool LDS>   // the environment's columns are staged in LDS for the walk
+// The walk is a chain of dependent look-ups.  The per-agent scalars it reads (status, time per cell, position, case,
+// decision, and the head entry of each agent's path) are fetched for all agents at once into LDS before it starts,
+// and its results (action, crash flag, decision, new head of the path) are collected there and stored after it: a
+// store inside the walk would have to complete before the next barrier, once per agent.  LDS = the environment's
+// columns are staged there too.
+template <bool LDS>
 __global__ __launch_bounds__(64) void rollout_apply_kernel(
     int16_t* __restrict__ cols_all, const int32_t* __restrict__ status_all, const int32_t* __restrict__ tpc_all,
     const int32_t* __restrict__ pos_all, const int32_t* __restrict__ init_all, const int32_t* __restrict__ branch_all,
@@ -241,24 +250,42 @@ __global__ __launch_bounds__(64) void rollout_apply_kernel(
     const int32_t* __restrict__ alt_count, const int32_t* __restrict__ alt_len, const int32_t* __restrict__ alt_cell,
     const uint32_t* __restrict__ alt_meta, const int16_t* __restrict__ alt_cols, int32_t* __restrict__ path_cell,
     uint32_t* __restrict__ path_meta, int32_t* __restrict__ path_head, int32_t* __restrict__ path_len, int A, int W,
-    int T1, int Lp, int cap_alt, int32_t* __restrict__ action_out, int32_t* __restrict__ crash_out,
+    int T1, int Lp, int cap_alt, int col_elems, int32_t* __restrict__ action_out, int32_t* __restrict__ crash_out,
     int32_t* __restrict__ net_out) {
   extern __shared__ __attribute__((aligned(16))) int16_t s_cols[];
   const int e = blockIdx.x, lane = threadIdx.x;
-  // The walk over the agents is a chain of dependent look-ups in the environment's columns (A*T1*2 bytes):
-  // they are staged in LDS when they fit, otherwise they stay in global memory (L2-resident for the walk).
+  // the columns (A*T1*2 bytes) go to LDS when they fit, otherwise they stay in global memory (L2-resident)
   int16_t* cols_env = cols_all + (size_t)e * A * T1;
   const int n_cols = A * T1;
-  if (LDS) {
+  int32_t* s_agent = reinterpret_cast<int32_t*>(s_cols + (LDS ? col_elems : 0));   // [12][A]
+  const size_t g0 = (size_t)e * A;
+  if (LDS)
     for (int i = lane; i < n_cols; i += 64) s_cols[i] = cols_env[i];
-    __syncthreads();
+  for (int o = lane; o < A; o += 64) {
+    const size_t g = g0 + o;
+    const int head = path_head[g], len = path_len[g];
+    int cell = -1;
+    unsigned meta = 0;
+    if (len >= 0 && head < len) {
+      cell = path_cell[g * Lp + head];
+      meta = path_meta[g * Lp + head];
   }
-  ColEnv m{LDS ? s_cols : cols_env, A, T1, status_all + (size_t)e * A, tpc_all + (size_t)e * A,
-           pos_all + (size_t)e * A};
+    s_agent[o] = status_all[g];
+    s_agent[A + o] = tpc_all[g];
+    s_agent[2 * A + o] = pos_all[g];
+    s_agent[3 * A + o] = branch_all[g];
+    s_agent[4 * A + o] = net_in[g];
+    s_agent[5 * A + o] = head;
+    s_agent[6 * A + o] = len;
+    s_agent[7 * A + o] = cell;
+    s_agent[8 * A + o] = (int32_t)meta;
+  }
+  __syncthreads();
+  ColEnv m{LDS ? s_cols : cols_env, A, T1, s_agent, s_agent + A, s_agent + 2 * A};
   for (int a = 0; a < A; a++) {
-    const size_t g = (size_t)e * A + a;
-    const int br = branch_all[g];
-    int net = net_in[g], action = 0, crash = 0;
+    const size_t g = g0 + a;
+    const int br = s_agent[3 * A + a];
+    int net = s_agent[4 * A + a], action = 0, crash = 0;
     int32_t* pc = path_cell + g * Lp;
     uint32_t* pm = path_meta + g * Lp;
     if (br == 0) {
@@ -277,20 +304,24 @@ __global__ __launch_bounds__(64) void rollout_apply_kernel(
         }
       }
     } else if (br == 2) {
+      // the agent commits to one of its alternatives: that path replaces its own, read from its first entry
       const int slot = alt_slot[g];
       const int n_alt = slot >= 0 ? alt_count[slot] : 0;
+      int len = -1;
+      unsigned meta0 = 0;
       if (n_alt > 0) {
         int b = best_all[g];
         if (b < 0 || b >= n_alt) b = 0;
         const size_t q = (size_t)slot * cap_alt + b;
-        const int len = alt_len[q];
+        len = alt_len[q];
+        if (len > 0) meta0 = alt_meta[q * Lp];
         for (int c = lane; c < T1; c += 64) m.row(a)[c] = alt_cols[q * T1 + c];
         for (int i = lane; i < len && i < Lp; i += 64) {
           pc[i] = alt_cell[q * Lp + i];
           pm[i] = alt_meta[q * Lp + i];
         }
         if (lane == 0) {
-          path_head[g] = 0;
+          s_agent[5 * A + a] = 0;
           path_len[g] = len;
         }
         __syncthreads();
@@ -305,33 +336,33 @@ __global__ __launch_bounds__(64) void rollout_apply_kernel(
           net = 0;
           action = 4;
         } else {
-          const int head = path_head[g], len = path_len[g];
-          if (len < 0 || head >= len) {
+          if (len <= 0) {
             action = 4;
           } else {
-            const int act = (pm[head] >> 8) & 0xFF;
+            const int act = (meta0 >> 8) & 0xFF;
             action = (act >= 1 && act <= 3) ? act : 0;
-            __syncthreads();
-            if (lane == 0) path_head[g] = head + 1;
+            if (lane == 0) s_agent[5 * A + a] = 1;
           }
           wave_update_bitmaps(m, a, true);
         }
       }
     } else if (br == 3) {
-      const int head = path_head[g], len = path_len[g];
-      crash = wave_check_crash(m, a, false, -1, path_next_cell(pc, pm, head, len, W)) ? 1 : 0;
+      const int head = s_agent[5 * A + a], len = s_agent[6 * A + a], cell = s_agent[7 * A + a];
+      const unsigned meta = (unsigned)s_agent[8 * A + a];
+      const bool on_path = len >= 0 && head < len;
+      const int act = (meta >> 8) & 0xFF, nh = (meta >> 16) & 3;
+      const int next_cell = !on_path ? -1 : (act == 4 ? cell : cell + dr(nh) * W + dc(nh));
+      crash = wave_check_crash(m, a, false, -1, next_cell) ? 1 : 0;
       if (crash) {
         net = 0;
         action = 4;
       } else {
         net = 1;
-        if (len < 0 || head >= len) {
+        if (!on_path) {
           action = 4;
         } else {
-          const int act = (pm[head] >> 8) & 0xFF;
           action = (act >= 1 && act <= 3) ? act : 0;
-          __syncthreads();
-          if (lane == 0) path_head[g] = head + 1;
+          if (lane == 0) s_agent[5 * A + a] = head + 1;
         }
         wave_update_bitmaps(m, a, false);
       }
@@ -340,11 +371,17 @@ __global__ __launch_bounds__(64) void rollout_apply_kernel(
       wave_update_bitmaps(m, a, false);
     }
     if (lane == 0) {
-      action_out[g] = action;
-      crash_out[g] = crash;
-      net_out[g] = net;
+      s_agent[9 * A + a] = action;
+      s_agent[10 * A + a] = crash;
+      s_agent[11 * A + a] = net;
     }
     __syncthreads();
+  }
+  for (int o = lane; o < A; o += 64) {
+    path_head[g0 + o] = s_agent[5 * A + o];
+    action_out[g0 + o] = s_agent[9 * A + o];
+    crash_out[g0 + o] = s_agent[10 * A + o];
+    net_out[g0 + o] = s_agent[11 * A + o];
   }
   if (LDS)
     for (int i = lane; i < n_cols; i += 64) cols_env[i] = s_cols[i];
@@ -723,18 +760,22 @@ extern "C" int flm_rollout_apply(int16_t* cols, const int32_t* status, const int
   if (!cols || !status || !tpc || !pos_cell || !init_cell || !branch || !net_in || !alt_slot || !best || !path_cell ||
       !path_meta || !path_head || !path_len || !action || !crash || !net_out)
     return FLM_E_ARG;
-  if (E <= 0 || A <= 0 || A > 4095 || W <= 0 || T1 <= 1 || T1 > 64 * FLM_STEP_KT || Lp <= 0 || cap_alt <= 0)
+  if (E <= 0 || A <= 0 || A > 512 || W <= 0 || T1 <= 1 || T1 > 64 * FLM_STEP_KT || Lp <= 0 || cap_alt <= 0)
     return FLM_E_ARG;
-  // up to 32 KiB of columns per environment go to LDS (several environments still share a CU)
+  // twelve words per agent and up to 32 KiB of columns per environment go to LDS (several environments still share
+  // a CU)
   const size_t col_bytes = ((size_t)A * T1 * sizeof(int16_t) + 15) & ~(size_t)15;
-  if (col_bytes <= 32 * 1024)
-    hipLaunchKernelGGL(flm::rollout_apply_kernel<true>, dim3(E), dim3(64), col_bytes, (hipStream_t)stream, cols, status, tpc,
-                       pos_cell, init_cell, branch, net_in, alt_slot, best, alt_count, alt_len, alt_cell, alt_meta,
-                       alt_cols, path_cell, path_meta, path_head, path_len, A, W, T1, Lp, cap_alt, action, crash, net_out);
-  else
-    hipLaunchKernelGGL(flm::rollout_apply_kernel<false>, dim3(E), dim3(64), 0, (hipStream_t)stream, cols, status, tpc,
-                       pos_cell, init_cell, branch, net_in, alt_slot, best, alt_count, alt_len, alt_cell, alt_meta,
-                       alt_cols, path_cell, path_meta, path_head, path_len, A, W, T1, Lp, cap_alt, action, crash, net_out);
+  const bool lds = col_bytes <= 32 * 1024;
+  const size_t shm = (lds ? col_bytes : 0) + (size_t)12 * A * sizeof(int32_t);
+  const int col_elems = (int)(col_bytes / sizeof(int16_t));
+#define FLM_APPLY(L)                                                                                                  \
+  hipLaunchKernelGGL(flm::rollout_apply_kernel<L>, dim3(E), dim3(64), shm, (hipStream_t)stream, cols, status, tpc,      \
+                     pos_cell, init_cell, branch, net_in, alt_slot, best, alt_count, alt_len, alt_cell, alt_meta,      \
+                     alt_cols, path_cell, path_meta, path_head, path_len, A, W, T1, Lp, cap_alt, col_elems, action,    \
+                     crash, net_out)
+  if (lds) FLM_APPLY(true);
+  else FLM_APPLY(false);
+#undef FLM_APPLY
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }

@@ -330,7 +330,7 @@ int flm_rollout_classify(const int32_t* status, const int32_t* pos_cell, const i
  *   written by flm_altpaths, alt_cols [n,cap_alt,T1] their planes in column form (flm_columns);
  *   cols, path_* are updated in place; action [E,A] out is the RailEnvActions value handed to the
  *   environment, crash [E,A] out, net_out [E,A] the decision after the crash checks.
- * T1 <= 512, A <= 4095. */
+ * T1 <= 512, A <= 512 (FLM_E_ARG beyond). */
 int flm_rollout_apply(int16_t* cols, const int32_t* status, const int32_t* tpc, const int32_t* pos_cell,
                       const int32_t* init_cell, const int32_t* branch, const int32_t* net_in, const int32_t* alt_slot,
                       const int32_t* best, const int32_t* alt_count, const int32_t* alt_len, const int32_t* alt_cell,
