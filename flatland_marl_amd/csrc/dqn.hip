@@ -1235,14 +1235,23 @@ static int launch_conv_u8(const uint8_t* obs_u8, const float* Wc, const float* b
 }  // namespace flm
 
 // K slices of the first dense layer (advantage and value streams side by side: 8 column tiles).  Two
-// workgroups of the split-operand kernel fit a CU, 512 on the chip: the slices are chosen so that the launch is
-// as close to a whole number of such rounds as the tiles allow (a launch of one and a half rounds takes two).
+// workgroups of the split-operand kernel fit a CU, 512 on the chip, and a launch takes as long as its fullest
+// CUs: the number of slices n is the one with the least estimated time, rounds(n) / n of a pass over the whole K
+// (rounds = launches' workgroups over 512, rounded up) plus n partial sums to write and reduce (about a millionth of
+// a pass per sample and slice).  512 samples: 16 slices, one round; 2,250 (a rollout step of 1024 x 10): 7 slices, 1,008
+// workgroups, instead of 3 slices that leave 80 CUs with one workgroup (measured: 0.527 against 0.553 ms per forward).
 static int fc1_k_slices(int B) {
   const long tiles = (long)((B + GBM - 1) / GBM) * 8;
-  long n = tiles >= 512 ? 1 : 512 / tiles;
-  if (n < 1) n = 1;
-  if (n > 32) n = 32;
-  return (int)n;
+  int best = 1;
+  double best_cost = 0;
+  for (int n = 1; n <= 32; n++) {
+    const double cost = (double)((tiles * n + 511) / 512) / n + n * (double)B * 1e-6;
+    if (n == 1 || cost < best_cost) {
+      best = n;
+      best_cost = cost;
+    }
+  }
+  return best;
 }
 
 using flm::DqnLayout;
