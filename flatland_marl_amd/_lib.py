@@ -64,6 +64,9 @@ _SIGNATURES = {
     "flm_dqn_learn_grads": [_p, _p, _p, _p, _p, _p, _p, C.c_float, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     "flm_observations_req_columns_rows": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "flm_replay_store": [_p, _i, _p, _i, _p, _p, C.c_long, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
+    "flm_replay_store_slots_workspace": [_i, _i],
+    "flm_replay_store_slots": [_p, _i, _p, _i, _p, _p, C.c_long, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i,
+                               _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "flm_replay_sample": [_i, _i, _u32, _u32, _p, _p],
     "flm_replay_gather": [_p, _p, _p, _p, _p, _p, _i, C.c_long, _p, _p, _p, _p, _p, _p],
     "flm_dqn_adam": [_p, _p, _p, _p, C.c_long, C.c_double, C.c_double, C.c_double, C.c_double, _i, _p],
@@ -72,7 +75,7 @@ _SIGNATURES = {
                                  C.c_double, _p],
 }
 
-_LONG_RESULT = {"flm_paths_columns_lds_bytes", "flm_paths_columns_workspace", "flm_dqn_param_count", "flm_dqn_grad_split", "flm_dqn_forward_workspace", "flm_dqn_learn_workspace",
+_LONG_RESULT = {"flm_paths_columns_lds_bytes", "flm_paths_columns_workspace", "flm_dqn_param_count", "flm_dqn_grad_split", "flm_replay_store_slots_workspace", "flm_dqn_forward_workspace", "flm_dqn_learn_workspace",
                 "flm_dqn_learn_workspace_u8"}
 _lib = None
 

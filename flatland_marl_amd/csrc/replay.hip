@@ -178,6 +178,181 @@ __global__ __launch_bounds__(256) void replay_store_rows_kernel(const uint8_t* _
     *reinterpret_cast<uint4*>(dst + o) = *reinterpret_cast<const uint4*>(src + o);
 }
 
+
+// ---- the feeding modes that keep an observation per agent between steps -------------------------------------------
+// The crash penalty (src/main.py:271-273) and switch-to-switch (src/main.py:280-296) work on curr_obs (the observation
+// an agent last acted on) and, switch-to-switch, buffer_obs / buffer_rew (the observation kept since the agent's last
+// "go" and the reward collected since).  Per step, in stream order:
+//   replay_slots_curr_kernel   every request with a row: curr_obs[agent] = that row, has_curr = 1;
+//   replay_slots_index_kernel  one workgroup lists the step's transitions in the order they enter the ring -
+//                              penalties (agents ascending: crash flag set and an observation to blame), then either
+//                              the default transitions (requests in order) or the matured switch-to-switch ones
+//                              (buffer_obs -> curr_obs, reward collected) followed by the stops (curr_obs -> curr_obs) -
+//                              with ring slots as deque(maxlen) would leave them, the scalars of each, and where its
+//                              two rows come from;
+//   replay_slots_rows_kernel   copies those rows into the ring;
+//   replay_slots_keep_kernel   switch-to-switch: a request that goes keeps curr_obs in buffer_obs;
+//   replay_slots_reward_kernel switch-to-switch: buffer_rew += reward for every agent holding a buffer_obs.
+constexpr unsigned SRC_OBS = 0u, SRC_CURR = 1u, SRC_BUF = 2u, SRC_NONE = 3u;   // upper two bits of a row source, index below
+
+__global__ __launch_bounds__(256) void replay_slots_curr_kernel(const int32_t* __restrict__ ready, int n_ready,
+                                                                const int32_t* __restrict__ sw, const int32_t* __restrict__ sel_row,
+                                                                int i0, const uint8_t* __restrict__ obs, long row_bytes,
+                                                                uint8_t* __restrict__ curr_obs, uint8_t* __restrict__ has_curr) {
+  const int i = i0 + blockIdx.y;
+  const int row = sel_row[i];
+  if (row < 0) return;
+  const int g = i < n_ready ? ready[i] : sw[i - n_ready];
+  const uint8_t* src = obs + (long)row * row_bytes;
+  uint8_t* dst = curr_obs + (long)g * row_bytes;
+  const long lo = (long)blockIdx.x * 16384;
+  const long hi = lo + 16384 < row_bytes ? lo + 16384 : row_bytes;
+  for (long o = lo + (long)threadIdx.x * 16; o < hi; o += 256 * 16)
+    *reinterpret_cast<uint4*>(dst + o) = *reinterpret_cast<const uint4*>(src + o);
+  if (blockIdx.x == 0 && threadIdx.x == 0) has_curr[g] = 1;
+}
+
+__global__ __launch_bounds__(1024) void replay_slots_index_kernel(
+    const int32_t* __restrict__ ready, int n_ready, const int32_t* __restrict__ sw, int n_switch,
+    const int32_t* __restrict__ sel_row, const int32_t* __restrict__ net, const double* __restrict__ reward,
+    const int32_t* __restrict__ done, const int32_t* __restrict__ crash, int n_agents, int crash_penalty, int switch2switch,
+    const uint8_t* __restrict__ has_curr, uint8_t* __restrict__ has_buf, double* __restrict__ buf_rew, int head, int capacity,
+    int64_t* __restrict__ ring_action, float* __restrict__ ring_reward, float* __restrict__ ring_done,
+    int32_t* __restrict__ desc, int max_t, int32_t* __restrict__ slot_req, int32_t* __restrict__ req_out,
+    int32_t* __restrict__ count_out) {
+  __shared__ int scratch[16];
+  const int tid = threadIdx.x, n = n_ready + n_switch;
+  auto agent_of = [&](int i) { return i < n_ready ? ready[i] : sw[i - n_ready]; };
+  // how many of each kind
+  int c_pen = 0, c_a = 0, c_b = 0;          // penalties; default or matured; stops
+  if (crash_penalty)
+    for (int g = tid; g < n_agents; g += 1024) c_pen += (crash[g] != 0 && has_curr[g]) ? 1 : 0;
+  for (int i = tid; i < n; i += 1024) {
+    if (sel_row[i] < 0) continue;
+    const int g = agent_of(i);
+    if (!switch2switch) {
+      c_a++;
+    } else {
+      c_a += has_buf[g] ? 1 : 0;
+      c_b += net[g] == 0 ? 1 : 0;
+    }
+  }
+  int n_pen, n_a, n_b;
+  block_int_scan(c_pen, scratch, &n_pen);
+  block_int_scan(c_a, scratch, &n_a);
+  block_int_scan(c_b, scratch, &n_b);
+  const int total = n_pen + n_a + n_b;
+  const int drop = total > capacity ? total - capacity : 0;
+  // transition t: its slot (or -1), its scalars, its row sources
+  auto emit = [&](int t, unsigned src_state, unsigned src_next, int64_t action, float rew, float dn) {
+    int sl = -1;
+    if (t >= drop) {
+      sl = (int)(((long)head + t - drop) % capacity);
+      ring_action[sl] = action;
+      ring_reward[sl] = rew;
+      ring_done[sl] = dn;
+    }
+    desc[t] = sl;
+    desc[max_t + t] = (int32_t)src_state;
+    desc[2 * max_t + t] = (int32_t)src_next;
+    return sl;
+  };
+  int base = 0;
+  if (crash_penalty)
+    for (int g0 = 0; g0 < n_agents; g0 += 1024) {
+      const int g = g0 + tid;
+      const bool hit = g < n_agents && crash[g] != 0 && has_curr[g];
+      int tot;
+      const int rank = base + block_flag_scan(hit, scratch, &tot);
+      base += tot;
+      if (hit) emit(rank, (SRC_CURR << 30) | (unsigned)g, (SRC_CURR << 30) | (unsigned)g, 1, -100.f, 1.f);
+    }
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + tid;
+    const bool ok = i < n && sel_row[i] >= 0;
+    const int g = i < n ? agent_of(i) : 0;
+    const bool first = ok && (!switch2switch || has_buf[g]);
+    int tot;
+    const int rank = base + block_flag_scan(first, scratch, &tot);
+    base += tot;
+    if (i < n) {
+      int sl = -1;
+      if (first && !switch2switch) {
+        // the decision stored is the one left by the crash checks (src/main.py:180, 225); the next state is written
+        // by the observation kernel afterwards
+        sl = emit(rank, (SRC_OBS << 30) | (unsigned)sel_row[i], SRC_NONE << 30, net[g], (float)reward[g], done[g] ? 1.f : 0.f);
+      } else if (first) {
+        // an observation kept since the previous decision meets the current one (src/main.py:283-287)
+        emit(rank, (SRC_BUF << 30) | (unsigned)g, (SRC_CURR << 30) | (unsigned)g, 1, (float)buf_rew[g], done[g] ? 1.f : 0.f);
+        has_buf[g] = 0;
+        buf_rew[g] = 0.0;
+      }
+      if (slot_req) slot_req[i] = sl;
+      if (req_out) req_out[i] = g;
+    }
+  }
+  if (switch2switch)
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+      const int i = i0 + tid;
+      const int g = i < n ? agent_of(i) : 0;
+      const bool stop = i < n && sel_row[i] >= 0 && net[g] == 0;
+      int tot;
+      const int rank = base + block_flag_scan(stop, scratch, &tot);
+      base += tot;
+      // stored with action 1, as the script does (src/main.py:289)
+      if (stop) emit(rank, (SRC_CURR << 30) | (unsigned)g, (SRC_CURR << 30) | (unsigned)g, 1, (float)reward[g], 0.f);
+    }
+  for (int t = total + tid; t < max_t; t += 1024) desc[t] = -1;
+  if (tid == 0) count_out[0] = total;
+}
+
+__global__ __launch_bounds__(256) void replay_slots_rows_kernel(const int32_t* __restrict__ desc, int max_t, int t0,
+                                                                const uint8_t* __restrict__ obs, const uint8_t* __restrict__ curr_obs,
+                                                                const uint8_t* __restrict__ buf_obs, long row_bytes,
+                                                                uint8_t* __restrict__ ring_state, uint8_t* __restrict__ ring_next) {
+  const int t = t0 + blockIdx.y;
+  const int sl = desc[t];
+  if (sl < 0) return;
+  auto source = [&](unsigned d) -> const uint8_t* {
+    const unsigned kind = d >> 30;
+    const long idx = (long)(d & 0x3FFFFFFFu);
+    return kind == SRC_OBS ? obs + idx * row_bytes : kind == SRC_CURR ? curr_obs + idx * row_bytes
+           : kind == SRC_BUF ? buf_obs + idx * row_bytes : nullptr;
+  };
+  const uint8_t* s0 = source((unsigned)desc[max_t + t]);
+  const uint8_t* s1 = source((unsigned)desc[2 * max_t + t]);
+  const long lo = (long)blockIdx.x * 16384;
+  const long hi = lo + 16384 < row_bytes ? lo + 16384 : row_bytes;
+  for (long o = lo + (long)threadIdx.x * 16; o < hi; o += 256 * 16) {
+    if (s0) *reinterpret_cast<uint4*>(ring_state + (long)sl * row_bytes + o) = *reinterpret_cast<const uint4*>(s0 + o);
+    if (s1) *reinterpret_cast<uint4*>(ring_next + (long)sl * row_bytes + o) = *reinterpret_cast<const uint4*>(s1 + o);
+  }
+}
+
+__global__ __launch_bounds__(256) void replay_slots_keep_kernel(const int32_t* __restrict__ ready, int n_ready,
+                                                                const int32_t* __restrict__ sw, const int32_t* __restrict__ sel_row,
+                                                                int i0, const int32_t* __restrict__ net, long row_bytes,
+                                                                const uint8_t* __restrict__ curr_obs, uint8_t* __restrict__ buf_obs,
+                                                                uint8_t* __restrict__ has_buf) {
+  const int i = i0 + blockIdx.y;
+  if (sel_row[i] < 0) return;
+  const int g = i < n_ready ? ready[i] : sw[i - n_ready];
+  if (net[g] != 1) return;
+  const uint8_t* src = curr_obs + (long)g * row_bytes;
+  uint8_t* dst = buf_obs + (long)g * row_bytes;
+  const long lo = (long)blockIdx.x * 16384;
+  const long hi = lo + 16384 < row_bytes ? lo + 16384 : row_bytes;
+  for (long o = lo + (long)threadIdx.x * 16; o < hi; o += 256 * 16)
+    *reinterpret_cast<uint4*>(dst + o) = *reinterpret_cast<const uint4*>(src + o);
+  if (blockIdx.x == 0 && threadIdx.x == 0) has_buf[g] = 1;
+}
+
+__global__ void replay_slots_reward_kernel(const uint8_t* __restrict__ has_buf, const double* __restrict__ reward, int n_agents,
+                                           double* __restrict__ buf_rew) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < n_agents && has_buf[g]) buf_rew[g] += reward[g];
+}
+
 }  // namespace flm
 
 extern "C" int flm_replay_store(const int32_t* ready, int n_ready, const int32_t* sw, int n_switch, const int32_t* sel_row,
@@ -201,6 +376,67 @@ extern "C" int flm_replay_store(const int32_t* ready, int n_ready, const int32_t
     const int cnt = n - lo < 65535 ? n - lo : 65535;
     hipLaunchKernelGGL(flm::replay_store_rows_kernel, dim3(pieces, (unsigned)cnt), dim3(256), 0, (hipStream_t)stream,
                        (const uint8_t*)obs, sel_row + lo, slot + lo, row_bytes, (uint8_t*)ring_state);
+    FLM_CHECK_LAUNCH();
+  }
+  return FLM_OK;
+}
+
+extern "C" long flm_replay_store_slots_workspace(int n_agents, int n_requests) {
+  if (n_agents <= 0 || n_requests < 0) return 0;
+  return 3L * ((long)n_agents + 2L * n_requests);
+}
+
+extern "C" int flm_replay_store_slots(const int32_t* ready, int n_ready, const int32_t* sw, int n_switch,
+                                      const int32_t* sel_row, const void* obs, long row_bytes, const int32_t* net,
+                                      const double* reward, const int32_t* done, const int32_t* crash, int n_agents,
+                                      int crash_penalty, int switch2switch, void* curr_obs, uint8_t* has_curr, void* buf_obs,
+                                      uint8_t* has_buf, double* buf_rew, int head, int capacity, void* ring_state,
+                                      void* ring_next, int64_t* ring_action, float* ring_reward, float* ring_done,
+                                      int32_t* workspace, int32_t* slot, int32_t* req_out, int32_t* count_out, void* stream) {
+  const long n_l = (long)n_ready + n_switch;
+  if (!net || !reward || !done || !crash || !curr_obs || !has_curr || !ring_state || !ring_next || !ring_action ||
+      !ring_reward || !ring_done || !workspace || !count_out)
+    return FLM_E_ARG;
+  if (n_ready < 0 || n_switch < 0 || n_l > 0x1FFFFFFF || n_agents <= 0 || n_agents > 0x1FFFFFFF) return FLM_E_ARG;
+  if (n_l > 0 && (!sel_row || !obs || !slot || !req_out || (n_ready > 0 && !ready) || (n_switch > 0 && !sw))) return FLM_E_ARG;
+  if (switch2switch && (!buf_obs || !has_buf || !buf_rew)) return FLM_E_ARG;
+  if (capacity <= 0 || head < 0 || head >= capacity || row_bytes <= 0 || (row_bytes & 15)) return FLM_E_ARG;
+  if (((uintptr_t)obs | (uintptr_t)ring_state | (uintptr_t)ring_next | (uintptr_t)curr_obs | (uintptr_t)buf_obs) & 15)
+    return FLM_E_ARG;
+  const int n = (int)n_l;
+  const long max_t_l = (long)n_agents + 2 * n_l;
+  if (max_t_l > 0x3FFFFFFF) return FLM_E_ARG;
+  const int max_t = (int)max_t_l;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned pieces = (unsigned)((row_bytes + 16383) / 16384);
+  for (int lo = 0; lo < n; lo += 65535) {                  // the grid's y extent is 65,535
+    const int cnt = n - lo < 65535 ? n - lo : 65535;
+    hipLaunchKernelGGL(flm::replay_slots_curr_kernel, dim3(pieces, (unsigned)cnt), dim3(256), 0, st, ready, n_ready, sw,
+                       sel_row, lo, (const uint8_t*)obs, row_bytes, (uint8_t*)curr_obs, has_curr);
+    FLM_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(flm::replay_slots_index_kernel, dim3(1), dim3(1024), 0, st, ready, n_ready, sw, n_switch, sel_row, net,
+                     reward, done, crash, n_agents, crash_penalty, switch2switch, has_curr, has_buf, buf_rew, head, capacity,
+                     ring_action, ring_reward, ring_done, workspace, max_t, slot, req_out, count_out);
+  FLM_CHECK_LAUNCH();
+  // at most this many transitions: every agent a penalty, every request one (default) or two (switch-to-switch)
+  const int most = (crash_penalty ? n_agents : 0) + (switch2switch ? 2 * n : n);
+  for (int lo = 0; lo < most; lo += 65535) {
+    const int cnt = most - lo < 65535 ? most - lo : 65535;
+    hipLaunchKernelGGL(flm::replay_slots_rows_kernel, dim3(pieces, (unsigned)cnt), dim3(256), 0, st, workspace, max_t, lo,
+                       (const uint8_t*)obs, (const uint8_t*)curr_obs, (const uint8_t*)buf_obs, row_bytes, (uint8_t*)ring_state,
+                       (uint8_t*)ring_next);
+    FLM_CHECK_LAUNCH();
+  }
+  if (switch2switch) {
+    for (int lo = 0; lo < n; lo += 65535) {
+      const int cnt = n - lo < 65535 ? n - lo : 65535;
+      hipLaunchKernelGGL(flm::replay_slots_keep_kernel, dim3(pieces, (unsigned)cnt), dim3(256), 0, st, ready, n_ready, sw,
+                         sel_row, lo, net, row_bytes, (const uint8_t*)curr_obs, (uint8_t*)buf_obs, has_buf);
+      FLM_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(flm::replay_slots_reward_kernel, dim3((unsigned)((n_agents + 255) / 256)), dim3(256), 0, st, has_buf,
+                       reward, n_agents, buf_rew);
     FLM_CHECK_LAUNCH();
   }
   return FLM_OK;

@@ -3,7 +3,7 @@ src/agent.py:134-198): a ring of transitions, uniform sampling without replaceme
 sampled rows gathered into buffers that are allocated once."""
 import torch
 
-from ._lib import call, ptr
+from ._lib import call, ptr, query
 
 
 class DeviceReplay:
@@ -73,6 +73,42 @@ class DeviceReplay:
              ptr(self._count), ro.stream)
         call("flm_observations_req_columns_rows", ptr(ro.cols), ptr(self._req), ptr(self._slot), n, ro.E, ro.A, b.Rp, b.T1,
              b.plane_stride, ptr(self.next_state), ro.stream)
+        k = int(self._count.item())
+        self.head = (self.head + min(k, self.capacity)) % self.capacity
+        self.size = min(self.capacity, self.size + k)
+        return k
+
+    def store_step_slots(self, ro, req_ready, req_switch, sel_row, obs, slots):
+        """The feeding modes that keep an observation per agent between steps (crash penalty, src/main.py:271-273;
+        switch-to-switch, src/main.py:280-296) and the default transitions beside them, for one rollout step of
+        every environment: flm_replay_store_slots.  req_ready / req_switch / sel_row / obs are None when nobody
+        consulted the network.  `slots` holds the per-agent state (curr_obs, has_curr, buf_obs, has_buf, buf_rew)
+        and the two flags.  Returns the number of transitions (one host read-back)."""
+        n1 = req_ready.numel() if req_ready is not None else 0
+        n2 = req_switch.numel() if req_switch is not None else 0
+        n = n1 + n2
+        dev = self.device
+        n_agents = ro.E * ro.A
+        if getattr(self, "_slot", None) is None or self._slot.numel() < max(n, 1):
+            cap = max(n, 1024)
+            self._slot = torch.empty((cap,), dtype=torch.int32, device=dev)
+            self._req = torch.empty((cap,), dtype=torch.int32, device=dev)
+            self._count = torch.zeros((1,), dtype=torch.int32, device=dev)
+        need = query("flm_replay_store_slots_workspace", n_agents, n)
+        if getattr(self, "_work", None) is None or self._work.numel() < need:
+            self._work = torch.empty((max(need, 3 * (n_agents + 2048)),), dtype=torch.int32, device=dev)
+        b = ro.b
+        s2s = bool(slots.switch2switch)
+        call("flm_replay_store_slots", ptr(req_ready) if n1 else None, n1, ptr(req_switch) if n2 else None, n2,
+             ptr(sel_row) if n else None, ptr(obs) if n else None, self.row_bytes, ptr(ro.net), ptr(ro.reward), ptr(ro.done),
+             ptr(ro.crash), n_agents, 1 if slots.crash_penalty else 0, 1 if s2s else 0, ptr(slots.curr_obs),
+             ptr(slots.has_curr), ptr(slots.buf_obs) if s2s else None, ptr(slots.has_buf) if s2s else None,
+             ptr(slots.buf_rew) if s2s else None, self.head, self.capacity, ptr(self.state), ptr(self.next_state),
+             ptr(self.action), ptr(self.reward), ptr(self.done), ptr(self._work), ptr(self._slot), ptr(self._req),
+             ptr(self._count), ro.stream)
+        if n and not s2s:
+            call("flm_observations_req_columns_rows", ptr(ro.cols), ptr(self._req), ptr(self._slot), n, ro.E, ro.A, b.Rp,
+                 b.T1, b.plane_stride, ptr(self.next_state), ro.stream)
         k = int(self._count.item())
         self.head = (self.head + min(k, self.capacity)) % self.capacity
         self.size = min(self.capacity, self.size + k)

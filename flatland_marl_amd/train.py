@@ -10,8 +10,10 @@ over E environments at once, everything resident on the GPU.
                    of the agents that consulted the network are stored (src/main.py:269-299, default mode) and
                    the learner runs once per `update_every` stored transitions (src/agent.py:55-67).
 
-                   Both replay-feeding modes of the script are there: the default one and switch-to-switch
-                   (src/main.py:280-296), as well as the crash penalty (src/main.py:271-273).
+                   Both replay-feeding modes of the script are there: the default one (flm_replay_store) and
+                   switch-to-switch (src/main.py:280-296), as well as the crash penalty (src/main.py:271-273;
+                   both flm_replay_store_slots): a step's transitions are listed and copied into the ring by
+                   kernels, one host read-back (their number) per step.
 
 Differences from the sequential script, all inherent to stepping many environments together: the learn
 steps of one rollout step sample a memory that already holds all of that step's transitions (and the
@@ -132,10 +134,10 @@ class BatchedTrainer:
         self.curr_obs = self.buf_obs = None
         if crash_penalty or switch2switch:
             self.curr_obs = torch.zeros((n, 3, b.plane_stride), dtype=torch.uint8, device=dev)
-            self.has_curr = torch.zeros((n,), dtype=torch.bool, device=dev)
+            self.has_curr = torch.zeros((n,), dtype=torch.uint8, device=dev)
         if switch2switch:
             self.buf_obs = torch.zeros((n, 3, b.plane_stride), dtype=torch.uint8, device=dev)
-            self.has_buf = torch.zeros((n,), dtype=torch.bool, device=dev)
+            self.has_buf = torch.zeros((n,), dtype=torch.uint8, device=dev)
             self.buf_rew = torch.zeros((n,), dtype=torch.float64, device=dev)
         self.max_learns_per_step = max_learns_per_step
         self.strict = strict
@@ -147,61 +149,6 @@ class BatchedTrainer:
         b = self.ro.b
         self.agent.learn_obs(self.replay.sample(self.agent.args.batch_size), self.agent.args.gamma, b.plane_stride)
         self.n_learn += 1
-
-    def _store_with_slots(self):
-        """The feeding modes that keep an observation per agent between steps: the crash penalty
-        (src/main.py:271-273) and switch-to-switch (src/main.py:280-296), and the default mode beside them."""
-        ro = self.ro
-        last = self.policy.last
-        n_new = 0
-        dev = ro.device
-        groups = [(r, o) for r, o, _ in (last or []) if r.numel()]
-        for req32, obs in groups:
-            self.curr_obs[req32.long()] = obs
-            self.has_curr[req32.long()] = True
-        if self.crash_penalty:                         # src/main.py:271-273: every agent whose check failed
-            idx = torch.nonzero((ro.crash.view(-1) != 0) & self.has_curr).view(-1)
-            k = idx.numel()
-            if k:
-                o = self.curr_obs[idx]
-                self.replay.add(o, torch.ones(k, dtype=torch.int64, device=dev),
-                                torch.full((k,), -100.0, device=dev), o, torch.ones(k, device=dev))
-                n_new += k
-        if not self.switch2switch:                     # src/main.py:275-278
-            for req32, obs in groups:
-                req = req32.long()
-                # the observation after the step: the agent's own plane against everybody's
-                next_obs = ro.consult_observations(req32.contiguous())
-                # the decision stored is the one after the crash checks (src/main.py:180, 225)
-                self.replay.add(obs, ro.net.view(-1)[req], ro.reward.view(-1)[req], next_obs, ro.done.view(-1)[req])
-                n_new += req.numel()
-        else:                                          # src/main.py:280-296
-            reward_all = ro.reward.view(-1)
-            if groups:
-                req = torch.cat([r for r, _ in groups]).long()
-                net_out = ro.net.view(-1)[req]
-                # an observation kept since the previous decision meets the current one
-                idx = req[self.has_buf[req]]
-                k = idx.numel()
-                if k:
-                    self.replay.add(self.buf_obs[idx], torch.ones(k, dtype=torch.int64, device=dev),
-                                    self.buf_rew[idx], self.curr_obs[idx], ro.done.view(-1)[idx])
-                    self.has_buf[idx] = False
-                    self.buf_rew[idx] = 0
-                    n_new += k
-                stop = req[net_out == 0]               # stored with action 1, as the script does (src/main.py:289)
-                k = stop.numel()
-                if k:
-                    o = self.curr_obs[stop]
-                    self.replay.add(o, torch.ones(k, dtype=torch.int64, device=dev), reward_all[stop], o,
-                                    torch.zeros(k, device=dev))
-                    n_new += k
-                go = req[net_out == 1]                 # kept until the agent's next decision
-                if go.numel():
-                    self.buf_obs[go] = self.curr_obs[go]
-                    self.has_buf[go] = True
-            self.buf_rew += torch.where(self.has_buf, reward_all, torch.zeros_like(reward_all))
-        return n_new
 
     def step(self, train=True):
         ro = self.ro
@@ -216,7 +163,11 @@ class BatchedTrainer:
                 req1, req2, obs, sel_row, _ = raw
                 n_new = self.replay.store_step(ro, req1, req2, sel_row, obs)
         elif train:
-            n_new = self._store_with_slots()
+            # crash penalty (src/main.py:271-273) and switch-to-switch (src/main.py:280-296): the observation each
+            # agent last acted on, and the one kept since its last "go", live in per-agent slots on the device
+            raw = self.policy.raw
+            req1, req2, obs, sel_row, _ = raw if raw is not None else (None, None, None, None, None)
+            n_new = self.replay.store_step_slots(ro, req1, req2, sel_row, obs, self)
         due = 0
         if train:
             self.n_transitions += n_new

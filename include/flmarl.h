@@ -485,6 +485,36 @@ int flm_replay_store(const int32_t* ready, int n_ready, const int32_t* sw, int n
                      int head, int capacity, void* ring_state, int64_t* ring_action, float* ring_reward,
                      float* ring_done, int32_t* slot, int32_t* req_out, int32_t* count_out, void* stream);
 
+/* flm_replay_store_slots: the replay feeding of one rollout step in the modes of the training script that keep an
+ * observation per agent between steps - the crash penalty (src/main.py:271-273) and switch-to-switch
+ * (src/main.py:280-296) - and the default transitions beside them (src/main.py:275-278).  Requests, sel_row, obs, net,
+ * reward, done, head, capacity and the ring arrays as for flm_replay_store; in addition
+ *   crash [n_agents] int32                 the step's crash flags (src/main.py:180, 225, 245)
+ *   crash_penalty, switch2switch           the script's two flags (src/main.py:394, 396)
+ *   curr_obs [n_agents,row_bytes], has_curr [n_agents] bytes   curr_obs of src/main.py:165,213 and whether it is set
+ *   buf_obs, has_buf, buf_rew [n_agents] double   buffer_obs / buffer_rew of src/main.py:123,131 (switch2switch only;
+ *                                          NULL otherwise); all five are read and updated
+ *   ring_next [capacity,row_bytes]         the ring's next-state rows
+ *   workspace int32 [flm_replay_store_slots_workspace(n_agents, n_ready + n_switch)]
+ * In stream order: every request with a row sets curr_obs / has_curr of its agent; the step's transitions are listed
+ * in the order they enter the ring - penalties (agents ascending with a crash flag and a curr_obs: state = next =
+ * curr_obs, action 1, reward -100, done), then either the default transitions of flm_replay_store or, switch2switch,
+ * first the matured ones (requests whose agent holds a buffer_obs: state buffer_obs, action 1, reward buffer_rew,
+ * next curr_obs, the step's done flag; buffer released) and then the stops (requests whose decision is 0: state =
+ * next = curr_obs, action 1, the step's reward, not done); a request that goes keeps curr_obs in buffer_obs, and
+ * buffer_rew collects the step's reward of every agent holding a buffer_obs.  Slots as in flm_replay_store (the last
+ * capacity transitions of an oversized step are kept).  Out: count_out [1]; without switch2switch also slot / req_out
+ * [n_ready + n_switch] for flm_observations_req_columns_rows, which writes the default transitions' next states.
+ * n_ready + n_switch may be 0 (penalties of agents that crashed without consulting the network; the reward
+ * collection). */
+long flm_replay_store_slots_workspace(int n_agents, int n_requests);
+int flm_replay_store_slots(const int32_t* ready, int n_ready, const int32_t* sw, int n_switch, const int32_t* sel_row,
+                           const void* obs, long row_bytes, const int32_t* net, const double* reward, const int32_t* done,
+                           const int32_t* crash, int n_agents, int crash_penalty, int switch2switch, void* curr_obs,
+                           uint8_t* has_curr, void* buf_obs, uint8_t* has_buf, double* buf_rew, int head, int capacity,
+                           void* ring_state, void* ring_next, int64_t* ring_action, float* ring_reward, float* ring_done,
+                           int32_t* workspace, int32_t* slot, int32_t* req_out, int32_t* count_out, void* stream);
+
 /* torch.optim.Adam step with default options over flat buffers (src/agent.py:38,113-115); step counts from 1. */
 int flm_dqn_adam(float* params, const float* grads, float* m, float* v, long n, double lr, double beta1, double beta2,
                  double eps, int step, void* stream);

@@ -147,15 +147,7 @@ def test_learning_pass_1024_environments_feeds_the_replay_as_the_script_does():
     tr = BatchedTrainer(ro, agent, start_eps=0.3, crash_penalty=True, max_learns_per_step=2, seed=3)
     w = torch.randint(-2 ** 40, 2 ** 40, (3 * b.plane_stride,), dtype=torch.int64, device=ro.device,
                       generator=torch.Generator(device=ro.device).manual_seed(1))
-    stored = []
-    add = tr.replay.add
-
-    def recording_add(state, action, reward, next_state, done):
-        hs, hn = _row_hash(state, w).cpu().numpy(), _row_hash(next_state, w).cpu().numpy()
-        ac, rw, dn = action.cpu().numpy(), reward.to(torch.float32).cpu().numpy(), done.cpu().numpy() != 0
-        stored.extend(zip(hs.tolist(), ac.tolist(), rw.tolist(), hn.tolist(), dn.tolist()))
-        add(state, action, reward, next_state, done)
-    tr.replay.add = recording_add
+    rp = tr.replay
 
     n = E * A
     curr = np.zeros(n, np.int64)                      # hash of the observation each agent last acted on (curr_obs)
@@ -164,8 +156,14 @@ def test_learning_pass_1024_environments_feeds_the_replay_as_the_script_does():
     total = 0
     before = agent.qnetwork_local.flat_params().clone()
     for t in range(20):
-        del stored[:]
-        tr.step(train=True)
+        head = rp.head
+        k = tr.step(train=True)
+        # what the step wrote into the ring
+        sl = (head + torch.arange(k, device=ro.device)) % rp.capacity
+        assert k <= rp.capacity
+        stored = list(zip(_row_hash(rp.state[sl], w).cpu().numpy().tolist(), rp.action[sl].cpu().numpy().tolist(),
+                          rp.reward[sl].cpu().numpy().tolist(), _row_hash(rp.next_state[sl], w).cpu().numpy().tolist(),
+                          (rp.done[sl].cpu().numpy() != 0).tolist()))
         update = np.zeros(n, bool)
         for req, obs, _ in (tr.policy.last or []):
             r = req.cpu().numpy()

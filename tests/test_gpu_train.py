@@ -93,15 +93,9 @@ def test_replay_feeding_follows_the_script(s2s, penalty):
     ro, agent, tr = _setup(E=3, A=12, depth=60, name="Test_2_Level_0", start_eps=0.4, crash_penalty=penalty,
                            switch2switch=s2s, replay_capacity=4000)
     agent.args.batch_size = 10 ** 9                           # never learn: only the feeding is under test
-    stored = []
-    add = tr.replay.add
-
-    def recording_add(state, action, reward, next_state, done):
-        for k in range(state.shape[0]):
-            stored.append((_hash(state[k]), int(action[k]), float(reward[k].to(torch.float32)), _hash(next_state[k]),
-                           bool(done[k])))
-        add(state, action, reward, next_state, done)
-    tr.replay.add = recording_add
+    rp = tr.replay
+    called = []
+    rp.add = lambda *a, **k: called.append(1)                # the tensor-by-tensor path must not run
 
     n = ro.E * ro.A
     curr_obs = [None] * n
@@ -110,9 +104,15 @@ def test_replay_feeding_follows_the_script(s2s, penalty):
     buffer_done = [False] * n
     total = 0
     for t in range(70):
-        del stored[:]
-        tr.step(train=True)
+        head = rp.head
+        k = tr.step(train=True)
         torch.cuda.synchronize()
+        # what the step wrote into the ring (flm_replay_store_slots)
+        stored = []
+        for j in range(k):
+            sl = (head + j) % rp.capacity
+            stored.append((_hash(rp.state[sl]), int(rp.action[sl]), float(rp.reward[sl]), _hash(rp.next_state[sl]),
+                           bool(rp.done[sl] != 0)))
         update = [False] * n
         for req, obs, _ in (tr.policy.last or []):
             for k, g in enumerate(req.cpu().numpy()):
@@ -148,7 +148,7 @@ def test_replay_feeding_follows_the_script(s2s, penalty):
             buffer_done[g] = done[g]
         assert Counter(stored) == Counter(want), t
         total += len(want)
-    assert total > 100
+    assert total > 100 and not called
     if s2s:
         assert any(x is not None for x in buffer_obs)
 
@@ -237,6 +237,117 @@ def test_store_kernel_keeps_the_last_capacity_transitions_of_an_oversized_step()
         sl, g = want_slot[i], req[i]
         assert np.array_equal(st[sl], obs[sel_row[i]]) and ac[sl] == net[g] and rw[sl] == np.float32(reward[g])
         assert dn[sl] == float(done[g] != 0)
+
+
+@pytest.mark.parametrize("s2s,penalty", [(False, True), (True, False), (True, True)])
+def test_store_slots_kernel_against_a_sequential_model(s2s, penalty):
+    """flm_replay_store_slots through the C ABI over four steps that share the per-agent slots, with a ring smaller than
+    one step's transitions: ring rows, scalars, slots and the per-agent state against the rules written out one
+    transition at a time (src/main.py:269-299) over a deque(maxlen=capacity)."""
+    import torch
+    from collections import deque
+    from flatland_marl_amd._lib import call, ptr, query
+    dev = "cuda"
+    rng = np.random.default_rng(11 + 2 * s2s + penalty)
+    n_agents, cap, row_bytes, rows = 300, 17, 48, 220
+    oversized = 0
+    z8 = lambda *sh: np.zeros(sh, np.uint8)
+    curr, has_curr, buf, has_buf, buf_rew = z8(n_agents, row_bytes), z8(n_agents), z8(n_agents, row_bytes), z8(n_agents), np.zeros(n_agents)
+    ring = deque(maxlen=cap)
+    d_curr, d_has_curr, d_buf, d_has_buf = (torch.as_tensor(x, device=dev) for x in (curr, has_curr, buf, has_buf))
+    d_buf_rew = torch.zeros(n_agents, dtype=torch.float64, device=dev)
+    ring_state = torch.zeros((cap, row_bytes), dtype=torch.uint8, device=dev)
+    ring_next = torch.zeros((cap, row_bytes), dtype=torch.uint8, device=dev)
+    ring_action = torch.zeros((cap,), dtype=torch.int64, device=dev)
+    ring_reward = torch.zeros((cap,), dtype=torch.float32, device=dev)
+    ring_done = torch.zeros((cap,), dtype=torch.float32, device=dev)
+    head = 5
+    slots_of = {}
+    for step in range(4):
+        perm = rng.permutation(n_agents)
+        n1, n2 = (0, 0) if step == 2 else (30, 50)               # one step in which nobody consulted the network
+        ready, sw = np.sort(perm[:n1]).astype(np.int32), np.sort(perm[n1:n1 + n2]).astype(np.int32)
+        n = n1 + n2
+        req = np.concatenate([ready, sw])
+        sel_row = rng.integers(0, rows, n).astype(np.int32)
+        sel_row[rng.random(n) < 0.2] = -1
+        obs = rng.integers(0, 255, (rows, row_bytes)).astype(np.uint8)
+        net = rng.integers(0, 2, n_agents).astype(np.int32)
+        reward = -rng.random(n_agents)
+        done = (rng.random(n_agents) < 0.2).astype(np.int32)
+        crash = (rng.random(n_agents) < 0.3).astype(np.int32)
+        # the model
+        ok = [i for i in range(n) if sel_row[i] >= 0]
+        for i in ok:
+            curr[req[i]] = obs[sel_row[i]]
+            has_curr[req[i]] = 1
+        trans = []
+        if penalty:
+            for g in range(n_agents):
+                if crash[g] and has_curr[g]:
+                    trans.append((curr[g].copy(), 1, np.float32(-100), curr[g].copy(), 1.0, None))
+        if not s2s:
+            for i in ok:
+                g = req[i]
+                trans.append((obs[sel_row[i]].copy(), int(net[g]), np.float32(reward[g]), None, float(done[g] != 0), i))
+        else:
+            for i in ok:
+                g = req[i]
+                if has_buf[g]:
+                    trans.append((buf[g].copy(), 1, np.float32(buf_rew[g]), curr[g].copy(), float(done[g] != 0), None))
+                    has_buf[g] = 0
+                    buf_rew[g] = 0.0
+            for i in ok:
+                g = req[i]
+                if net[g] == 0:
+                    trans.append((curr[g].copy(), 1, np.float32(reward[g]), curr[g].copy(), 0.0, None))
+            for i in ok:
+                g = req[i]
+                if net[g] == 1:
+                    buf[g] = curr[g]
+                    has_buf[g] = 1
+            buf_rew += np.where(has_buf != 0, reward, 0.0)
+        # the kernel
+        t = lambda x: torch.as_tensor(x, device=dev)
+        d = dict(ready=t(ready), sw=t(sw), sel_row=t(sel_row), obs=t(obs), net=t(net), reward=t(reward), done=t(done), crash=t(crash))
+        work = torch.empty((query("flm_replay_store_slots_workspace", n_agents, n),), dtype=torch.int32, device=dev)
+        slot = torch.full((max(n, 1),), -7, dtype=torch.int32, device=dev)
+        req_out = torch.full((max(n, 1),), -7, dtype=torch.int32, device=dev)
+        count = torch.zeros((1,), dtype=torch.int32, device=dev)
+        call("flm_replay_store_slots", ptr(d["ready"]) if n1 else None, n1, ptr(d["sw"]) if n2 else None, n2,
+             ptr(d["sel_row"]) if n else None, ptr(d["obs"]) if n else None, row_bytes, ptr(d["net"]), ptr(d["reward"]),
+             ptr(d["done"]), ptr(d["crash"]), n_agents, int(penalty), int(s2s), ptr(d_curr), ptr(d_has_curr),
+             ptr(d_buf) if s2s else None, ptr(d_has_buf) if s2s else None, ptr(d_buf_rew) if s2s else None, head, cap,
+             ptr(ring_state), ptr(ring_next), ptr(ring_action), ptr(ring_reward), ptr(ring_done), ptr(work), ptr(slot),
+             ptr(req_out), ptr(count), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        k = int(count.item())
+        assert k == len(trans), step
+        oversized += k > cap                                     # only the last `cap` transitions of such a step survive
+        # ring slots of the transitions kept, in order
+        kept = trans[-cap:] if k > cap else trans
+        first_slot = head
+        st, nx = ring_state.cpu().numpy(), ring_next.cpu().numpy()
+        ac, rw, dn = ring_action.cpu().numpy(), ring_reward.cpu().numpy(), ring_done.cpu().numpy()
+        sl_req = slot.cpu().numpy()
+        if n and not s2s:
+            assert np.array_equal(req_out.cpu().numpy()[:n], req)
+            want_slot = np.full(n, -1, np.int32)
+        for j, (s0, a0, r0, s1, d0, i_req) in enumerate(kept):
+            sl = (first_slot + j) % cap
+            assert np.array_equal(st[sl], s0) and ac[sl] == a0 and rw[sl] == r0 and dn[sl] == d0, (step, j)
+            if s1 is not None:
+                assert np.array_equal(nx[sl], s1), (step, j)
+            else:
+                want_slot[i_req] = sl                            # next state left to the observation kernel
+        if n and not s2s:
+            assert np.array_equal(sl_req[:n], want_slot), step
+        head = (head + min(k, cap)) % cap
+        assert np.array_equal(d_curr.cpu().numpy(), curr) and np.array_equal(d_has_curr.cpu().numpy(), has_curr), step
+        if s2s:
+            assert np.array_equal(d_buf.cpu().numpy(), buf) and np.array_equal(d_has_buf.cpu().numpy(), has_buf), step
+            assert np.array_equal(d_buf_rew.cpu().numpy(), buf_rew), step
+    assert oversized >= 2
 
 
 def test_policy_select_kernel():
