@@ -264,9 +264,13 @@ __global__ __launch_bounds__(64) void altpaths_kernel(
       n_alt++;
     }
   }
-  if (live && j == 0) {
-    alt_count[g] = err ? 0 : n_alt;
-    err_out[g] = err;
+  if (live) {
+    // unused alternatives have length 0 (the caller need not clear the array)
+    for (int q = (err ? 0 : n_alt) + j; q < cap_alt; q += G) out_len[q] = 0;
+    if (j == 0) {
+      alt_count[g] = err ? 0 : n_alt;
+      err_out[g] = err;
+    }
   }
 }
 

@@ -69,7 +69,10 @@ class RolloutBatch:
         self.agent_err = torch.zeros((E, A), **i32)          # sticky: first error code seen for the agent
         self.ready_list = torch.zeros((E * A,), **i32)      # agents in case 1 / case 2 this step, ascending
         self.switch_list = torch.zeros((E * A,), **i32)
-        self.req_counts = torch.zeros((3,), **i32)           # departing agents, agents before a switch, network rows
+        # departing agents, agents before a switch, network rows: the kernels write these three numbers straight into
+        # pinned host memory, the host reads them after an event (no copy in between)
+        self.req_counts = torch.zeros((3,), dtype=torch.int32).pin_memory()
+        self._counts_event = torch.cuda.Event()
         self._req_ws = torch.zeros((2 * ((E * A + 1023) // 1024),), **i32)
         self._dummy_i32 = torch.zeros((1,), **i32)
         self._dummy_i16 = torch.zeros((1,), dtype=torch.int16, device=dev)
@@ -169,7 +172,6 @@ class RolloutBatch:
                    err=pool["err"][:n], cols=pool["cols"][:n], col_err=pool["col_err"][:n], req=req,
                    row_offset=pool["row_offset"][:n + 1], row_req=pool["row_req"][:n_ready + n * K],
                    row_own=pool["row_own"][:n_ready + n * K])
-        alt["len"].zero_()
         for lo in range(0, n, MAX_REQ):
             hi = min(n, lo + MAX_REQ)
             call("flm_altpaths", ptr(b.grid), ptr(b.cell_idx), ptr(b.dist), ptr(b.succ_table()), ptr(b.choice_table()),
@@ -252,7 +254,7 @@ class RolloutBatch:
              ptr(b.start_cell), self.E, self.A, ptr(self.ready_list), ptr(self.switch_list), ptr(self.req_counts),
              ptr(self.alt_slot), ptr(self._net), ptr(self._best), ptr(b.pos_cell), ptr(b.direction), ptr(b.status),
              ptr(self._req_ws), self.stream)
-        n_ready, n_switch = self.req_counts[:2].tolist()      # the one host read-back of the step's sizes
+        n_ready, n_switch = self.read_counts()[:2]             # the host waits for the step's sizes
         req_ready, req_switch = self.ready_list[:n_ready], self.switch_list[:n_switch]
         alt = self.alternatives(req_switch, req_ready) if n_switch else None
         info = dict(t=self.t, branch=self.branch, req_ready=req_ready, req_switch=req_switch, alt=alt,
@@ -263,6 +265,12 @@ class RolloutBatch:
         self.t += 1
         info["net_in"], info["best"] = net_in, best
         return info
+
+    def read_counts(self):
+        """[departing agents, agents before a switch, network rows] as the kernels enqueued so far leave them."""
+        self._counts_event.record(self.b.stream)
+        self._counts_event.synchronize()
+        return self.req_counts.tolist()
 
     def flagged_agents(self):
         """(agents whose path or alternatives raised in the reference's terms, agents that hit a capacity of this

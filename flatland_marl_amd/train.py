@@ -58,10 +58,12 @@ class DQNPolicy:
     def q_values(self, ro, obs_u8):
         b = ro.b
         n = obs_u8.shape[0]
-        q = torch.empty((n, 2), dtype=torch.float32, device=obs_u8.device)
         per = 64 * 3 * b.Rp * 4                            # the convolution output dominates the workspace
         chunk = max(1, self.chunk_bytes // per)
         net = self.agent.qnetwork_local
+        if n <= chunk:
+            return net.forward_obs(obs_u8, b.plane_stride)
+        q = torch.empty((n, 2), dtype=torch.float32, device=obs_u8.device)
         for lo in range(0, n, chunk):
             hi = min(n, lo + chunk)
             q[lo:hi] = net.forward_obs(obs_u8[lo:hi], b.plane_stride)
@@ -75,7 +77,7 @@ class DQNPolicy:
         if n1 + n2 == 0:
             return net, best
         if alt is not None:
-            rows = int(ro.req_counts[2].item())            # departing agents + all alternatives
+            rows = ro.read_counts()[2]                     # departing agents + all alternatives
             obs = ro.consult_observations(alt["row_req"][:rows], alt["cols"].view(-1, ro.b.T1), own_row=alt["row_own"][:rows]) \
                 if rows else None
         else:

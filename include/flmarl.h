@@ -276,7 +276,8 @@ int flm_reorder_rails(const uint8_t* obs_in, uint8_t* obs_out, int n, int Rp, in
  *   (or NULL: every step is then worked out from the grid); idx_cell [E,capCells] int32: the grid cell of every
  *   rail cell (flm_state_index), or NULL; with all three and tables that fit the LDS a request's descents run on
  *   staged copies
- *   alt_count [n_req] out; alt_len [n_req,cap_alt] out; alt_cell/alt_meta [n_req,cap_alt,Lcap] out in the
+ *   alt_count [n_req] out; alt_len [n_req,cap_alt] out (0 for the alternatives beyond alt_count);
+ *   alt_cell/alt_meta [n_req,cap_alt,Lcap] out in the
  *   path encoding of flm_shortest_paths; err [n_req] out (FLM_AGENT_ASSERT_ERROR where the reference's
  *   assertions at :108/:125 fail, FLM_AGENT_OVERFLOW when the branches before the first plain cells number
  *   more than cap_alt, or Lcap or 32 consecutive switch cells are exceeded).  Lcap >= max_depth + 4,

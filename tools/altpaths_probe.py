@@ -33,7 +33,7 @@ def main():
     call("flm_rollout_requests", ptr(ro.branch), ptr(ro.status), ptr(ro.pos), ptr(ro.heading), ptr(b.start_cell), ro.E, ro.A,
          ptr(ro.ready_list), ptr(ro.switch_list), ptr(ro.req_counts), ptr(ro.alt_slot), ptr(ro._net), ptr(ro._best),
          ptr(b.pos_cell), ptr(b.direction), ptr(b.status), ptr(ro._req_ws), ro.stream)
-    n_ready, n_switch = ro.req_counts[:2].tolist()
+    n_ready, n_switch = ro.read_counts()[:2]
     req = ro.switch_list[:n_switch].clone()
     print("requests", n_switch, "departing", n_ready, "cap_cells", b.cap_cells, "Lp", ro.Lp)
     K, dev = ro.cap_alt, ro.device
