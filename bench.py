@@ -208,8 +208,9 @@ def dqn_sample(device, B=512, max_rails=100, depth=150):
     agent = DQNAgent(a, action_space=2, bitmap_height=H3)
     g = torch.Generator().manual_seed(0)
     ps = (max_rails * T1 + 255) // 256 * 256
-    obs = torch.randint(0, 3, (B, 3, ps), generator=g, dtype=torch.uint8).to(device)
-    obs_n = torch.randint(0, 3, (B, 3, ps), generator=g, dtype=torch.uint8).to(device)
+    # states and next states as the device replay memory hands them out: one buffer, the next states behind the states
+    both = torch.randint(0, 3, (2 * B, 3, ps), generator=g, dtype=torch.uint8).to(device)
+    obs, obs_n = both[:B], both[B:]
     act = torch.randint(0, 2, (B,), generator=g).to(device)
     r = torch.randn(B, generator=g).to(device)
     d = (torch.rand(B, generator=g) < 0.1).float().to(device)

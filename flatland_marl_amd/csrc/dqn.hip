@@ -1475,9 +1475,17 @@ static int learn_dense_half(const float* local, const float* target, const float
   // The local network on the states and, under double DQN (where its view of the next states picks the action), on
   // the next states as well: two convolutions into adjacent halves, then the dense layers once over 2B samples (the
   // weights of the first dense layer are read once, and its K slices are half as many).
-  if ((rc = dqn_conv_stage(local, s_u8 ? nullptr : s, s_u8, plane_stride, B, H3, T1, NA, w.x1, stream))) return rc;
-  if (double_dqn && (rc = dqn_conv_stage(local, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, NA, w.x1n, stream)))
-    return rc;
+  // (One launch when the next states lie right behind the states in memory, as a replay memory that gathers both into
+  // one buffer leaves them: the same rows, fewer idle waves at the end of the launch.)
+  const bool adjacent = double_dqn && (s_u8 ? sn_u8 == s_u8 + (size_t)B * 3 * plane_stride : s_next == s + (size_t)B * H3 * T1) &&
+                        (long)2 * B * H3 < (1L << 31) && (s_u8 || B > 8);   // (float input: the same kernel either way)
+  if (adjacent) {
+    if ((rc = dqn_conv_stage(local, s_u8 ? nullptr : s, s_u8, plane_stride, 2 * B, H3, T1, NA, w.x1, stream))) return rc;
+  } else {
+    if ((rc = dqn_conv_stage(local, s_u8 ? nullptr : s, s_u8, plane_stride, B, H3, T1, NA, w.x1, stream))) return rc;
+    if (double_dqn && (rc = dqn_conv_stage(local, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, NA, w.x1n, stream)))
+      return rc;
+  }
   if ((rc = dqn_dense_stage(local, double_dqn ? 2 * B : B, H3, T1, NA, w.x1, w.hid, w.part, w.q, stream))) return rc;
   if ((rc = dqn_forward_impl(target, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, NA, w.x1t, w.hidt, w.part, w.qt,
                              stream)))

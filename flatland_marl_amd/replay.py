@@ -65,7 +65,9 @@ class DeviceReplay:
             cap = max(n, 1024)
             self._slot = torch.empty((cap,), dtype=torch.int32, device=dev)
             self._req = torch.empty((cap,), dtype=torch.int32, device=dev)
-            self._count = torch.zeros((1,), dtype=torch.int32, device=dev)
+            # the kernels write the step's number of transitions into pinned host memory; the host reads it after an event
+            self._count = torch.zeros((1,), dtype=torch.int32).pin_memory()
+            self._count_event = torch.cuda.Event()
         b = ro.b
         call("flm_replay_store", ptr(req_ready) if n1 else None, n1, ptr(req_switch) if n2 else None, n2, ptr(sel_row),
              ptr(obs), self.row_bytes, ptr(ro.net), ptr(ro.reward), ptr(ro.done), self.head, self.capacity,
@@ -73,7 +75,9 @@ class DeviceReplay:
              ptr(self._count), ro.stream)
         call("flm_observations_req_columns_rows", ptr(ro.cols), ptr(self._req), ptr(self._slot), n, ro.E, ro.A, b.Rp, b.T1,
              b.plane_stride, ptr(self.next_state), ro.stream)
-        k = int(self._count.item())
+        self._count_event.record(ro.b.stream)
+        self._count_event.synchronize()
+        k = int(self._count[0])
         self.head = (self.head + min(k, self.capacity)) % self.capacity
         self.size = min(self.capacity, self.size + k)
         return k
@@ -93,7 +97,9 @@ class DeviceReplay:
             cap = max(n, 1024)
             self._slot = torch.empty((cap,), dtype=torch.int32, device=dev)
             self._req = torch.empty((cap,), dtype=torch.int32, device=dev)
-            self._count = torch.zeros((1,), dtype=torch.int32, device=dev)
+            # the kernels write the step's number of transitions into pinned host memory; the host reads it after an event
+            self._count = torch.zeros((1,), dtype=torch.int32).pin_memory()
+            self._count_event = torch.cuda.Event()
         need = query("flm_replay_store_slots_workspace", n_agents, n)
         if getattr(self, "_work", None) is None or self._work.numel() < need:
             self._work = torch.empty((max(need, 3 * (n_agents + 2048)),), dtype=torch.int32, device=dev)
@@ -109,7 +115,9 @@ class DeviceReplay:
         if n and not s2s:
             call("flm_observations_req_columns_rows", ptr(ro.cols), ptr(self._req), ptr(self._slot), n, ro.E, ro.A, b.Rp,
                  b.T1, b.plane_stride, ptr(self.next_state), ro.stream)
-        k = int(self._count.item())
+        self._count_event.record(ro.b.stream)
+        self._count_event.synchronize()
+        k = int(self._count[0])
         self.head = (self.head + min(k, self.capacity)) % self.capacity
         self.size = min(self.capacity, self.size + k)
         return k
@@ -130,9 +138,11 @@ class DeviceReplay:
         B = int(batch_size)
         if self._out is None or self._out[0].shape[0] != B:
             dev = self.device
-            self._out = (torch.empty((B,) + self.row_shape, dtype=self.dtype, device=dev),
-                         torch.empty((B,), dtype=torch.int64, device=dev), torch.empty((B,), dtype=torch.float32, device=dev),
-                         torch.empty((B,) + self.row_shape, dtype=self.dtype, device=dev),
+            # states and next states in one buffer, the next states right behind the states: the learner's
+            # convolution then takes both in one launch
+            both = torch.empty((2 * B,) + self.row_shape, dtype=self.dtype, device=dev)
+            self._out = (both[:B], torch.empty((B,), dtype=torch.int64, device=dev),
+                         torch.empty((B,), dtype=torch.float32, device=dev), both[B:],
                          torch.empty((B,), dtype=torch.float32, device=dev),
                          torch.empty((B,), dtype=torch.int32, device=dev))
         s, a, r, sn, d, idx = self._out

@@ -545,3 +545,43 @@ def test_learn_step_in_two_phases_gives_the_same_bits(u8):
     call(name + "_phase", *head, ptr(got), ptr(loss_g), 2, st)
     torch.cuda.synchronize()
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("u8", [True, False])
+def test_learn_step_with_next_states_behind_the_states_gives_the_same_bits(u8):
+    """When the next states lie right behind the states in memory (the device replay memory's layout) the local
+    network's two convolutions are one launch: the same gradients and loss bit for bit as from separate buffers."""
+    from flatland_marl_amd._lib import call, ptr, query
+    dev = "cuda"
+    B, Rp, T1, NA = 45, 11, 53, 2
+    H3 = 3 * Rp
+    ps = (Rp * T1 + 255) // 256 * 256
+    g = torch.Generator().manual_seed(9)
+    n = query("flm_dqn_param_count", H3, T1, NA)
+    local = (torch.randn(n, generator=g) * 0.05).to(dev)
+    target = (torch.randn(n, generator=g) * 0.05).to(dev)
+    act = torch.randint(0, NA, (B,), generator=g).to(dev)
+    rew = torch.randn(B, generator=g).to(dev)
+    done = (torch.rand(B, generator=g) < 0.2).float().to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    if u8:
+        both = torch.randint(0, 3, (2 * B, 3, ps), generator=g, dtype=torch.uint8).to(dev)
+        ws = torch.empty(query("flm_dqn_learn_workspace_u8", B, Rp, T1, NA), device=dev)
+        name = "flm_dqn_learn_grads_u8"
+        args = lambda s, sn: (ptr(local), ptr(target), ptr(s), ptr(sn), ps, ptr(act), ptr(rew), ptr(done), 0.97, 1, B, Rp, T1,
+                              NA, ptr(ws))
+    else:
+        both = torch.randint(-1, 3, (2 * B, H3, T1), generator=g).float().to(dev)
+        ws = torch.empty(query("flm_dqn_learn_workspace", B, H3, T1, NA), device=dev)
+        name = "flm_dqn_learn_grads"
+        args = lambda s, sn: (ptr(local), ptr(target), ptr(s), ptr(sn), ptr(act), ptr(rew), ptr(done), 0.97, 1, B, H3, T1, NA,
+                              ptr(ws))
+    apart_s, apart_n = both[:B].clone(), both[B:].clone()
+    want, loss_w = torch.zeros(n, device=dev), torch.zeros(1, device=dev)
+    call(name, *args(apart_s, apart_n), ptr(want), ptr(loss_w), st)
+    got, loss_g = torch.zeros(n, device=dev), torch.zeros(1, device=dev)
+    call(name, *args(both[:B], both[B:]), ptr(got), ptr(loss_g), st)
+    torch.cuda.synchronize()
+    assert both[B:].data_ptr() == both.data_ptr() + B * both[0].numel() * both.element_size()
+    assert torch.equal(got, want) and torch.equal(loss_g, loss_w)
+    assert float(want.abs().max()) > 0

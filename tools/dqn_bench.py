@@ -62,6 +62,9 @@ def main():
     obs_n = torch.randint(0, 3, (B, 3, ps), generator=g, dtype=torch.uint8).cuda()
     t = timed(lambda: agent.learn_obs((obs, act, r, obs_n, d), 0.99, ps))
     out["learn_u8_ms"] = t
+    both = torch.cat([obs, obs_n])                             # the replay memory's layout: next states behind the states
+    t = timed(lambda: agent.learn_obs((both[:B], act, r, both[B:], d), 0.99, ps))
+    out["learn_u8_adjacent_ms"] = t
     print(json.dumps(out))
 
 
