@@ -1208,6 +1208,195 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void conv_u8_kernel(
   }
 }
 
+// ---- the convolution's weight and bias gradients straight from uint8 observations --------------------------------
+// dWc[c][k] = sum over samples b and rows h of dx1[b][c][h] * s[b][h][k],  dbias[c] = sum of dx1[b][c][h].
+// On the matrix cores with the rows (b,h) as the inner dimension, 16 rows per instruction: A = dx1, fp32 split into
+// three bf16 terms, B = the observation bytes, exact in bf16, so three instructions per 16 rows and 32x32 tile and
+// every partial product exact (the product from float states needs six, on tiles half empty).  Column T1 of B is all
+// ones: its column of the result is the bias gradient.  Both operands come straight from memory: a lane's eight
+// consecutive rows of one channel of dx1 are contiguous, and its eight rows of one byte column of s are eight byte
+// loads (no transposition through LDS).
+// One workgroup per CU, eight waves = 2 channel halves x 4; the four waves of a half share out the 16-row chunks of the
+// workgroup's samples (sample blockIdx.x, blockIdx.x + gridDim.x, ...), each accumulating a [32, 32*NT] tile in
+// registers with the next chunk's loads in flight; the four tiles of a half meet in LDS in a fixed order, the workgroup
+// writes one partial [64, 32*NT], and conv_wgrad_reduce_kernel adds the workgroups' partials in a fixed order.
+template <int NT>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_u8_kernel(const float* __restrict__ dx1, const uint8_t* __restrict__ obs,
+                                                               int B, int Rp, int T1, int plane_stride,
+                                                               float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float wg_lds[];   // [2 halves][3 waves][NT * 16][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = wave & 1, q = wave >> 1;
+  const int n = lane & 31, kg = lane >> 5;
+  const int H3 = 3 * Rp;
+  const int NC = (H3 + 15) >> 4;                       // chunks of 16 rows per sample
+  const int G = gridDim.x;
+  const int n_task = ((B - 1 - (int)blockIdx.x) / G + 1) * NC;
+  const int c = 32 * half + n;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int kt = 0; kt < NT; kt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[kt][r] = 0.f;
+
+  // this lane's share of chunk t: eight rows of channel c of dx1 (zero past the sample's last row), the same eight
+  // rows of NT byte columns of s, and which of the rows are signed (plane 0).  Every load is unconditional, from an
+  // address clamped into the arrays, and what must not count is replaced afterwards: no branch stands between the
+  // loads, so those of the next chunk stay in flight under the products of this one.
+  const int kcol[2] = {min(32 * (NT - 1) + n, T1 - 1), 0};
+  auto fetch = [&](int t, float (&a)[8], unsigned (&bb)[NT][8], unsigned& sgn) {
+    t = min(t, n_task - 1);
+    const int si = t / NC, j = t - si * NC;
+    const int b = (int)blockIdx.x + si * G;
+    const int hb = 16 * j + 8 * kg;
+    const float* pa = dx1 + ((long)b * 64 + c) * H3;
+    const uint8_t* ob = obs + (long)b * 3 * plane_stride;
+    sgn = 0;
+    // eight consecutive floats as two 16-byte loads (4-byte aligned is enough for global memory; one load per lane
+    // and cache line instead of four).  Past the sample's last row they run into the next channel's rows or, at the
+    // very end of dx1, into the caller's next buffer (at most 15 floats; the workspace continues there): masked below.
+    struct __attribute__((aligned(4))) F4 { float v[4]; };
+    const F4 lo = *reinterpret_cast<const F4*>(pa + hb), hi = *reinterpret_cast<const F4*>(pa + hb + 4);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      a[i] = lo.v[i];
+      a[4 + i] = hi.v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int h = min(hb + i, H3 - 1);               // (a row past the end is multiplied by zero)
+      const int pl = (h >= Rp ? 1 : 0) + (h >= 2 * Rp ? 1 : 0);
+      const uint8_t* row = ob + (long)pl * plane_stride + (long)(h - pl * Rp) * T1;
+      sgn |= pl == 0 ? 1u << i : 0u;
+#pragma unroll
+      for (int kt = 0; kt < NT; kt++) bb[kt][i] = row[kt + 1 < NT ? 32 * kt + n : kcol[0]];
+    }
+  };
+  // (after the loads) rows past the sample's end and columns past the horizon: zero, the bias column: one
+  auto mask = [&](int t, float (&a)[8], unsigned (&bb)[NT][8]) {
+    t = min(t, n_task - 1);
+    const int j = t % NC;
+    const int hb = 16 * j + 8 * kg;
+    const int k = 32 * (NT - 1) + n;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      a[i] = hb + i < H3 ? a[i] : 0.f;
+      bb[NT - 1][i] = k < T1 ? bb[NT - 1][i] : (k == T1 ? 1u : 0u);
+    }
+  };
+  auto compute = [&](const float (&a)[8], const unsigned (&bb)[NT][8], unsigned sgn) {
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) split3(a[i], h[i], m[i], l[i]);
+    bf16x8 fa[3];
+    fa[0] = __builtin_bit_cast(bf16x8, make_uint4(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]), pack_hi16(h[4], h[5]), pack_hi16(h[6], h[7])));
+    fa[1] = __builtin_bit_cast(bf16x8, make_uint4(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]), pack_hi16(m[4], m[5]), pack_hi16(m[6], m[7])));
+    fa[2] = __builtin_bit_cast(bf16x8, make_uint4(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]), pack_hi16(l[4], l[5]), pack_hi16(l[6], l[7])));
+    bf16x8 fb[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++) {
+      unsigned f[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int v = (sgn >> i) & 1u ? (int)(signed char)bb[kt][i] : (int)bb[kt][i];
+        f[i] = __float_as_uint((float)v);             // -1..255: exact in the upper half of the word
+      }
+      fb[kt] = __builtin_bit_cast(bf16x8, make_uint4(pack_hi16(f[0], f[1]), pack_hi16(f[2], f[3]), pack_hi16(f[4], f[5]), pack_hi16(f[6], f[7])));
+    }
+#pragma unroll
+    for (int sp = 2; sp >= 0; sp--)                    // smallest terms first
+#pragma unroll
+      for (int kt = 0; kt < NT; kt++) acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sp], fb[kt], acc[kt], 0, 0, 0);
+  };
+
+  float a0[8], a1[8];
+  unsigned b0[NT][8], b1[NT][8], s0 = 0, s1 = 0;
+  fetch(q, a0, b0, s0);
+  for (int t = q; t < n_task; t += 8) {
+    fetch(t + 4, a1, b1, s1);
+    mask(t, a0, b0);
+    compute(a0, b0, s0);
+    fetch(t + 8, a0, b0, s0);
+    if (t + 4 < n_task) {
+      mask(t + 4, a1, b1);
+      compute(a1, b1, s1);
+    }
+  }
+  // the four tiles of a half, added in wave order
+  if (q > 0) {
+    float* slot = wg_lds + (size_t)((half * 3 + (q - 1)) * NT * 16) * 64;
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) slot[(kt * 16 + r) * 64 + lane] = acc[kt][r];
+  }
+  __syncthreads();
+  if (q == 0) {
+    for (int qq = 0; qq < 3; qq++) {
+      const float* slot = wg_lds + (size_t)((half * 3 + qq) * NT * 16) * 64;
+#pragma unroll
+      for (int kt = 0; kt < NT; kt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[kt][r] += slot[(kt * 16 + r) * 64 + lane];
+    }
+    float* out = part + (size_t)blockIdx.x * 64 * (32 * NT);
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int cc = 32 * half + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        out[(size_t)cc * (32 * NT) + 32 * kt + n] = acc[kt][r];
+      }
+  }
+}
+
+// dW[c][k] (k < T1) and db[c] (k == T1) = sum over the G workgroup partials part[g][c][k] of row width W: sixteen waves
+// take every sixteenth partial each (two sums in flight per lane), their sums meet in LDS in wave order
+__global__ __launch_bounds__(1024) void conv_wgrad_reduce_kernel(const float* __restrict__ part, int G, int W, int T1,
+                                                                 float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float sm[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + lane;
+  const bool valid = idx < 64 * (T1 + 1);
+  const int c = valid ? idx / (T1 + 1) : 0, k = valid ? idx - c * (T1 + 1) : 0;
+  const float* p = part + (size_t)c * W + k;
+  const size_t gs = (size_t)64 * W;
+  float s0 = 0.f, s1 = 0.f;
+  int g = w;
+  for (; g + 16 < G; g += 32) {
+    s0 += p[(size_t)g * gs];
+    s1 += p[(size_t)(g + 16) * gs];
+  }
+  if (g < G) s0 += p[(size_t)g * gs];
+  sm[w][lane] = s0 + s1;
+  __syncthreads();
+  if (w == 0 && valid) {
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) v += sm[i][lane];
+    if (k < T1) dW[(size_t)c * T1 + k] = v;
+    else db[c] = v;
+  }
+}
+
+// the byte form of the convolution's weight gradient covers horizons up to depth 158 (five column tiles with the
+// bias column) 
+static int conv_wgrad_u8_tiles(int T1) { return T1 + 1 <= 160 ? (T1 + 1 + 31) / 32 : 0; }
+static int conv_wgrad_u8_groups(int B) { return B < 256 ? B : 256; }
+
+template <int NT>
+static int launch_conv_wgrad_u8(const float* dx1, const uint8_t* obs, int B, int Rp, int T1, int plane_stride, float* part,
+                                float* dW, float* db, hipStream_t stream) {
+  const int G = conv_wgrad_u8_groups(B);
+  const size_t lds = (size_t)6 * NT * 16 * 64 * sizeof(float);
+  FLM_RAISE_LDS_ONCE((conv_wgrad_u8_kernel<NT>));
+  hipLaunchKernelGGL((conv_wgrad_u8_kernel<NT>), dim3(G), dim3(512), lds, stream, dx1, obs, B, Rp, T1, plane_stride, part);
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((64 * (T1 + 1) + 63) / 64)), dim3(1024), 0, stream, part, G,
+                     32 * NT, T1, dW, db);
+  if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
+  return FLM_OK;
+}
+
 static size_t conv_u8_lds(int T1, int nwave, bool bf, int tile_rows = 64) {
   const size_t rows = ((size_t)nwave * tile_rows * CV_ASTRIDE(T1) + 15) & ~(size_t)15;
   // BF: 16 spare bytes behind the bias: the last row's third word may lie behind the rows of the last wave
@@ -1421,6 +1610,14 @@ static long learn_part_floats(int B) {
   return one > two ? one : two;
 }
 
+// the convolution's weight-gradient partials: one [64,T1] per sample (from float states) or one [64,32*tiles] per
+// workgroup (from bytes)
+static long learn_cpart_floats(int B, int T1) {
+  const long per_sample = (long)B * 64 * T1;
+  const long per_group = (long)flm::conv_wgrad_u8_groups(B) * 64 * 32 * flm::conv_wgrad_u8_tiles(T1);
+  return per_sample > per_group ? per_sample : per_group;
+}
+
 // workspace floats needed by flm_dqn_learn_grads
 extern "C" long flm_dqn_learn_workspace(int B, int H3, int T1, int NA) {
   if (!actions_ok(NA)) return 0;
@@ -1428,7 +1625,7 @@ extern "C" long flm_dqn_learn_workspace(int B, int H3, int T1, int NA) {
   return 3 * act                                              // three forwards
          + (long)B * 1024                                     // dhid
          + (long)B * 64 * H3                                  // dx1
-         + (long)B * 64 * T1                                  // per-sample conv weight partials
+         + learn_cpart_floats(B, T1)                          // conv weight-gradient partials
          + learn_part_floats(B)                               // split-K partials of the first dense layer
          + (((5L * NA + 2) * B + 64 + 3) & ~3L);              // three q's, dq, dadv; dval, squared errors (whole 16 bytes)
 }
@@ -1453,7 +1650,7 @@ struct LearnWorkspace {
     dhid = hidt + n_hid;
     dx1 = dhid + n_hid;
     cpart = dx1 + n_x1;
-    part = cpart + (long)B * 64 * T1;
+    part = cpart + learn_cpart_floats(B, T1);
     q = part + learn_part_floats(B);
     qn = q + (long)NA * B; qt = qn + (long)NA * B; dq = qt + (long)NA * B;
     dadv = dq + (long)NA * B; dval = dadv + (long)NA * B; sq = dval + B;
@@ -1466,7 +1663,7 @@ static int learn_dense_half(const float* local, const float* target, const float
                             int NA, const LearnWorkspace& w, float* grads, float* loss_out, hipStream_t stream) {
   DqnLayout L(H3, T1, NA);
   int rc;
-  if (s_u8) {
+  if (s_u8 && !flm::conv_wgrad_u8_tiles(T1)) {      // (the byte form of the weight gradient needs no float copy)
     if ((long)B * 3 > 65535) return FLM_E_ARG;
     hipLaunchKernelGGL(flm::obs_to_f32_kernel, dim3(flm::obs_to_f32_pieces(H3 / 3, T1), B * 3), dim3(256), 0, stream, s_u8, B,
                        H3 / 3, T1, plane_stride, const_cast<float*>(s));
@@ -1517,8 +1714,8 @@ static int learn_dense_half(const float* local, const float* target, const float
   return FLM_OK;
 }
 
-static int learn_conv_half(const float* local, const float* s, int B, int H3, int T1, int NA, const LearnWorkspace& w,
-                           float* grads, hipStream_t stream) {
+static int learn_conv_half(const float* local, const float* s, const uint8_t* s_u8, int plane_stride, int B, int H3, int T1,
+                           int NA, const LearnWorkspace& w, float* grads, hipStream_t stream) {
   DqnLayout L(H3, T1, NA);
   int rc;
   // gradient w.r.t. the conv activations: dx1 = [dhid_adv dhid_val] * [W_adv; W_val], zero where x1 == 0: one product
@@ -1530,7 +1727,21 @@ static int learn_conv_half(const float* local, const float* s, int B, int H3, in
     g.b_break_k = 512; g.b_break_off = (L.v1_w - L.a1_w) - 512L * L.K1; g.x_slowest = 1;
     if ((rc = flm::launch_gemm<true, false, flm::EPI_MASK>(g, 1, stream))) return rc;
   }
-  // conv weights: per sample dWc_b[64,T1] = dx1_b[64,H3] * s_b[H3,T1], then a fixed-order sum over the batch
+  // conv weights and bias from the observation bytes where the horizon allows: one launch and its reduction
+  const int nt = s_u8 ? flm::conv_wgrad_u8_tiles(T1) : 0;
+  if (nt) {
+    float* dW = grads + L.conv_w;
+    float* db = grads + L.conv_b;
+    switch (nt) {
+      case 1: rc = flm::launch_conv_wgrad_u8<1>(w.dx1, s_u8, B, H3 / 3, T1, plane_stride, w.cpart, dW, db, stream); break;
+      case 2: rc = flm::launch_conv_wgrad_u8<2>(w.dx1, s_u8, B, H3 / 3, T1, plane_stride, w.cpart, dW, db, stream); break;
+      case 3: rc = flm::launch_conv_wgrad_u8<3>(w.dx1, s_u8, B, H3 / 3, T1, plane_stride, w.cpart, dW, db, stream); break;
+      case 4: rc = flm::launch_conv_wgrad_u8<4>(w.dx1, s_u8, B, H3 / 3, T1, plane_stride, w.cpart, dW, db, stream); break;
+      default: rc = flm::launch_conv_wgrad_u8<5>(w.dx1, s_u8, B, H3 / 3, T1, plane_stride, w.cpart, dW, db, stream); break;
+    }
+    return rc;
+  }
+  // from float states: per sample dWc_b[64,T1] = dx1_b[64,H3] * s_b[H3,T1], then a fixed-order sum over the batch
   {
     GemmArgs g{};
     g.A = w.dx1; g.B = s; g.C = w.cpart;
@@ -1558,7 +1769,7 @@ static int learn_grads_impl(const float* local, const float* target, const float
   if (phase != 2)
     rc = learn_dense_half(local, target, s, s_next, s_u8, sn_u8, plane_stride, action, reward, done, gamma, double_dqn, B, H3,
                           T1, NA, w, grads, loss_out, stream);
-  if (rc == FLM_OK && phase != 1) rc = learn_conv_half(local, s, B, H3, T1, NA, w, grads, stream);
+  if (rc == FLM_OK && phase != 1) rc = learn_conv_half(local, s, s_u8, plane_stride, B, H3, T1, NA, w, grads, stream);
   return rc;
 }
 
