@@ -356,12 +356,16 @@ def test_forward_from_uint8_observations_vs_torch(B, Rp, T1, pad):
     assert close(got, want)
 
 
-@pytest.mark.parametrize("Rp,T1,B,ps", [(37, 61, 96, 2304), (11, 151, 70, 1664 + 16), (5, 255, 33, 1280), (1, 100, 9, 112)])
+@pytest.mark.parametrize("Rp,T1,B,ps", [(37, 61, 96, 2304), (11, 151, 70, 1664 + 16), (5, 255, 33, 1280), (1, 100, 9, 112),
+                                        (7, 159, 300, 1120), (6, 31, 40, 192), (9, 32, 261, 288), (5, 160, 20, 800),
+                                        (23, 96, 17, 2208)])
 def test_learn_from_uint8_observations_matches_float_learn(Rp, T1, B, ps):
     """flm_dqn_learn_grads_u8 (bytes in, as the device replay memory stores them) against flm_dqn_learn_grads on
-    the float expansion of the same observations: loss and every gradient within 1e-5 relative.  Horizons on both
-    sides of the sizes the convolution's weight-gradient kernel takes (97..256 time steps), plane strides that are
-    and are not multiples of 256, a single rail per plane."""
+    the float expansion of the same observations: loss and every gradient within 1e-5 relative, the convolution's
+    own gradients also within 1e-5 of their own largest.  The byte form of the convolution's weight gradient takes
+    horizons up to 159 columns (one to five column tiles, the bias column first or last in its tile: 31, 32, 96, 159),
+    longer ones (160, 255) go through the float copy; batches below and above the 256 workgroups of that kernel;
+    plane strides that are and are not multiples of 256; a single rail per plane; heat counts up to 255."""
     import types
     import torch
     from flatland_marl_amd.agent import DQNAgent
@@ -375,6 +379,7 @@ def test_learn_from_uint8_observations_matches_float_learn(Rp, T1, B, ps):
     obs = torch.zeros((2, B, 3, ps), dtype=torch.uint8)
     obs[:, :, 0, :Rp * T1] = torch.randint(-1, 2, (2, B, Rp * T1), generator=g).to(torch.int8).view(torch.uint8)
     obs[:, :, 1:, :Rp * T1] = torch.randint(0, 4, (2, B, 2, Rp * T1), generator=g).to(torch.uint8)
+    obs[:, :, 2, :Rp * T1:7] = torch.randint(0, 256, obs[:, :, 2, :Rp * T1:7].shape, generator=g).to(torch.uint8)
     obs = obs.cuda()
     f = torch.empty((2, B, 3 * Rp, T1), dtype=torch.float32, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
@@ -396,6 +401,9 @@ def test_learn_from_uint8_observations_matches_float_learn(Rp, T1, B, ps):
     assert torch.allclose(loss[0], loss[1], rtol=1e-5)
     scale = grads[0].abs().max().item()
     assert scale > 0 and (grads[0] - grads[1]).abs().max().item() <= 1e-5 * scale
+    n_conv = query("flm_dqn_grad_split", 3 * Rp, T1, 2)          # the convolution's weights and bias come first
+    conv_scale = grads[0, :n_conv].abs().max().item()
+    assert conv_scale > 0 and (grads[0, :n_conv] - grads[1, :n_conv]).abs().max().item() <= 1e-5 * conv_scale
 
 
 def test_learn_shape_of_the_benchmark_elementwise_vs_torch():
