@@ -970,12 +970,29 @@ __device__ __forceinline__ uint2 bytes_to_bf16(unsigned w, int mode, bool sg) {
 // WPL: words a lane fetches per row (rows of up to 64*WPL words); NWAVE: waves per workgroup; JT: tiles of 32 rows a
 // wave works on at a time (2: 64 rows share every filter fragment read; 1: half the rows per wave in LDS, so that
 // twice the waves fit a CU and hide one another's memory latency)
+struct ConvSecondJob {
+  const uint8_t* obs;
+  const float* Wc;
+  const float* bias;
+  long M, obs_bytes;
+  float* x1;
+  unsigned first_wg;     // >= gridDim.x: no second job
+};
+
 template <int WPL, int NWAVE, bool BF, int JT>
 __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void conv_u8_kernel(
     const uint8_t* __restrict__ obs, const float* __restrict__ Wc, const float* __restrict__ bias, long M, int Rp, int T1,
-    int H3, int plane_stride, long obs_bytes, float* __restrict__ x1) {
+    int H3, int plane_stride, long obs_bytes, float* __restrict__ x1, ConvSecondJob j2) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cv_lds[];
   constexpr int CV_TILE = 32 * JT;
+  // a launch may carry a second convolution of the same shape with its own filters, input and output (the target
+  // network beside the local one in a learn step): the workgroups from j2.first_wg on work on it
+  const bool second = blockIdx.x >= j2.first_wg;
+  if (second) {
+    obs = j2.obs; Wc = j2.Wc; bias = j2.bias; M = j2.M; obs_bytes = j2.obs_bytes; x1 = j2.x1;
+  }
+  const unsigned n_wg = second ? gridDim.x - j2.first_wg : min(gridDim.x, j2.first_wg);
+  const unsigned wg = second ? blockIdx.x - j2.first_wg : blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int astr = CV_ASTRIDE(T1);
@@ -1015,7 +1032,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void conv_u8_kernel(
 
   const unsigned uM = (unsigned)M, uH3 = (unsigned)H3, uRp = (unsigned)Rp;      // M < 2^31 (checked by the host)
   const unsigned NT = (uM + CV_TILE - 1) / CV_TILE;
-  const unsigned GW = gridDim.x * NWAVE;
+  const unsigned GW = n_wg * NWAVE;
   // byte offsets are taken from the 4-byte aligned address at or below obs
   const unsigned mis = (unsigned)(reinterpret_cast<size_t>(obs) & 3);
   const uint8_t* obs_al = obs - mis;
@@ -1086,9 +1103,9 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void conv_u8_kernel(
   // Software pipeline over this wave's tiles: while tile t is multiplied its successor's bytes are in flight;
   // they are written to LDS right after the products, and only then are the outputs of tile t stored, so that
   // those stores drain during the next tile's products instead of in front of a wait.
-  // (tile t goes to workgroup t % gridDim.x: when the tiles are not a multiple of the waves, the waves with one
+  // (tile t goes to workgroup t % n_wg: when the tiles are not a multiple of the waves, the waves with one
   // tile more are spread over all CUs instead of filling the first few)
-  unsigned t = __builtin_amdgcn_readfirstlane(wave * gridDim.x + blockIdx.x);
+  unsigned t = __builtin_amdgcn_readfirstlane(wave * n_wg + wg);
   unsigned cur_rows = 0, cur_drel = 0;
   long cur_out0 = 0;
   int cur_os = 0;
@@ -1403,9 +1420,19 @@ static size_t conv_u8_lds(int T1, int nwave, bool bf, int tile_rows = 64) {
   return bf ? rows + (size_t)3 * 64 * CV_BROW(T1) + 64 * 4 + 16 : rows + ((size_t)((T1 + 1) & ~1) * CV_WSTRIDE + 64) * 4;
 }
 
+// second (optional): another convolution of the same shape in the same launch - its own filters (params2: a network's
+// flat parameters), observations and output; the 256 workgroups are shared out by the number of tiles
+struct ConvSecond {
+  const float* Wc;
+  const float* bias;
+  const uint8_t* obs;
+  long M, obs_bytes;
+  float* x1;
+};
+
 template <int WPL, int NWAVE, bool BF, int JT = 2>
 static int launch_conv_u8(const uint8_t* obs_u8, const float* Wc, const float* bias, long M, int Rp, int T1, int H3,
-                          int plane_stride, long obs_bytes, float* x1, hipStream_t stream) {
+                          int plane_stride, long obs_bytes, float* x1, hipStream_t stream, const ConvSecond* second = nullptr) {
   constexpr int CV_TILE = 32 * JT;
   const size_t lds = conv_u8_lds(T1, NWAVE, BF, CV_TILE);
   if (lds > 160 * 1024 - 512) return FLM_E_ARG;
@@ -1415,8 +1442,23 @@ static int launch_conv_u8(const uint8_t* obs_u8, const float* Wc, const float* b
   long wgs = (tiles + NWAVE - 1) / NWAVE;
   if (wgs > 256) wgs = 256;
   if (wgs < 1) wgs = 1;
+  ConvSecondJob j2{};
+  j2.first_wg = 0xFFFFFFFFu;
+  if (second) {
+    const long tiles2 = (second->M + CV_TILE - 1) / CV_TILE;
+    long wgs2 = (tiles2 + NWAVE - 1) / NWAVE;
+    if (wgs2 < 1) wgs2 = 1;
+    if (wgs + wgs2 > 256) {                   // share the CUs by the work
+      wgs = (256 * tiles + (tiles + tiles2) / 2) / (tiles + tiles2);
+      if (wgs < 1) wgs = 1;
+      if (wgs > 255) wgs = 255;
+      wgs2 = 256 - wgs;
+    }
+    j2 = ConvSecondJob{second->obs, second->Wc, second->bias, second->M, second->obs_bytes, second->x1, (unsigned)wgs};
+    wgs += wgs2;
+  }
   hipLaunchKernelGGL((conv_u8_kernel<WPL, NWAVE, BF, JT>), dim3((unsigned)wgs), dim3(64 * NWAVE), lds, stream, obs_u8, Wc, bias,
-                     M, Rp, T1, H3, plane_stride, obs_bytes, x1);
+                     M, Rp, T1, H3, plane_stride, obs_bytes, x1, j2);
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
 }
@@ -1463,8 +1505,10 @@ static bool dqn_rows_path(const float* params, const DqnLayout& L, int B, const 
 
 // The convolution: x1[B,64,H3] from x, the float input [B,H3,T1], or (x == nullptr) from obs_u8 [B,3,plane_stride]
 // with H3 = 3*Rp.
+// params2 (byte input only): a second network's convolution over obs2 [B2,3,plane_stride] into x1_2, in the same launch.
 static int dqn_conv_stage(const float* params, const float* x, const uint8_t* obs_u8, int plane_stride, int B, int H3,
-                          int T1, int NA, float* x1, hipStream_t stream) {
+                          int T1, int NA, float* x1, hipStream_t stream, const float* params2 = nullptr,
+                          const uint8_t* obs2 = nullptr, int B2 = 0, float* x1_2 = nullptr) {
   DqnLayout L(H3, T1, NA);
   GemmArgs g{};
   int rc;
@@ -1490,21 +1534,28 @@ static int dqn_conv_stage(const float* params, const float* x, const uint8_t* ob
     const float* cw = params + L.conv_w;
     const float* cb = params + L.conv_b;
     const size_t cap = 160 * 1024 - 512;
+    flm::ConvSecond sec{};
+    const flm::ConvSecond* second = nullptr;
+    if (params2) {
+      if ((long)B2 * H3 >= (1L << 31)) return FLM_E_ARG;
+      sec = flm::ConvSecond{params2 + L.conv_w, params2 + L.conv_b, obs2, (long)B2 * H3, (long)B2 * 3 * plane_stride, x1_2};
+      second = &sec;
+    }
     // on the bf16 matrix cores while the split filter bank fits the LDS beside the rows of the waves: sixteen waves
     // with 32 rows each first (four per SIMD hide one another's memory latency), then eight waves with 64 or 32
     // rows, then four with 32 (depth 300: the bank alone is 120 KB); beyond that on fp32 instructions
     if (nword <= 64 && flm::conv_u8_lds(T1, 16, true, 32) <= cap)
-      rc = flm::launch_conv_u8<1, 16, true, 1>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
+      rc = flm::launch_conv_u8<1, 16, true, 1>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream, second);
     else if (nword <= 64 && flm::conv_u8_lds(T1, 8, true) <= cap)
-      rc = flm::launch_conv_u8<1, 8, true>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
+      rc = flm::launch_conv_u8<1, 8, true>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream, second);
     else if (nword <= 64 && flm::conv_u8_lds(T1, 8, true, 32) <= cap)       // (the LDS of four waves with 64 rows)
-      rc = flm::launch_conv_u8<1, 8, true, 1>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
+      rc = flm::launch_conv_u8<1, 8, true, 1>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream, second);
     else if (nword <= 128 && flm::conv_u8_lds(T1, 4, true, 32) <= cap)      // long horizons: the bank leaves room for four
-      rc = flm::launch_conv_u8<2, 4, true, 1>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
+      rc = flm::launch_conv_u8<2, 4, true, 1>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream, second);
     else if (nword <= 64)
-      rc = flm::launch_conv_u8<1, 4, false>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
+      rc = flm::launch_conv_u8<1, 4, false>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream, second);
     else if (nword <= 128)
-      rc = flm::launch_conv_u8<2, 4, false>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream);
+      rc = flm::launch_conv_u8<2, 4, false>(obs_u8, cw, cb, M, H3 / 3, T1, H3, plane_stride, obs_bytes, x1, stream, second);
     else
       rc = FLM_E_ARG;
     if (rc) return rc;
@@ -1676,17 +1727,26 @@ static int learn_dense_half(const float* local, const float* target, const float
   // one buffer leaves them: the same rows, fewer idle waves at the end of the launch.)
   const bool adjacent = double_dqn && (s_u8 ? sn_u8 == s_u8 + (size_t)B * 3 * plane_stride : s_next == s + (size_t)B * H3 * T1) &&
                         (long)2 * B * H3 < (1L << 31) && (s_u8 || B > 8);   // (float input: the same kernel either way)
-  if (adjacent) {
-    if ((rc = dqn_conv_stage(local, s_u8 ? nullptr : s, s_u8, plane_stride, 2 * B, H3, T1, NA, w.x1, stream))) return rc;
+  bool target_conv_done = false;
+  if (adjacent && s_u8) {
+    // ... and the target network's convolution over the next states rides in the same launch
+    if ((rc = dqn_conv_stage(local, nullptr, s_u8, plane_stride, 2 * B, H3, T1, NA, w.x1, stream, target, sn_u8, B, w.x1t)))
+      return rc;
+    target_conv_done = true;
+  } else if (adjacent) {
+    if ((rc = dqn_conv_stage(local, s, nullptr, plane_stride, 2 * B, H3, T1, NA, w.x1, stream))) return rc;
   } else {
     if ((rc = dqn_conv_stage(local, s_u8 ? nullptr : s, s_u8, plane_stride, B, H3, T1, NA, w.x1, stream))) return rc;
     if (double_dqn && (rc = dqn_conv_stage(local, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, NA, w.x1n, stream)))
       return rc;
   }
   if ((rc = dqn_dense_stage(local, double_dqn ? 2 * B : B, H3, T1, NA, w.x1, w.hid, w.part, w.q, stream))) return rc;
-  if ((rc = dqn_forward_impl(target, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, NA, w.x1t, w.hidt, w.part, w.qt,
-                             stream)))
-    return rc;
+  if (target_conv_done)
+    rc = dqn_dense_stage(target, B, H3, T1, NA, w.x1t, w.hidt, w.part, w.qt, stream);
+  else
+    rc = dqn_forward_impl(target, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, NA, w.x1t, w.hidt, w.part, w.qt,
+                          stream);
+  if (rc) return rc;
   if (double_dqn)
     hipLaunchKernelGGL(flm::td_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, w.q, w.qn, w.qt, action, reward, done,
                        gamma, B, NA, w.dq, w.sq);
