@@ -390,7 +390,9 @@ __global__ void reduce_bias_relu_kernel(const float* __restrict__ part, int nz, 
 }
 
 // column sums: out[n] = sum_m X[m*ld + n], one workgroup per 64 columns, fixed summation order
-__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ X, int M, int N, long ld, float* __restrict__ out) {
+// (columns from n_split on go to out1: two destinations that are not adjacent, one launch)
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ X, int M, int N, long ld, float* __restrict__ out,
+                                                      int n_split, float* __restrict__ out1) {
   __shared__ float s[16][64];
   const int lane = threadIdx.x & 63, n = blockIdx.x * 64 + lane, w = threadIdx.x >> 6;
   // 16 waves split the rows; four independent partial sums per lane keep four loads in flight; every
@@ -412,7 +414,8 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
     float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; i++) acc += s[i][lane];
-    out[n] = acc;
+    if (n < n_split) out[n] = acc;
+    else out1[n - n_split] = acc;
   }
 }
 
@@ -701,20 +704,36 @@ __global__ __launch_bounds__(256) void fc1_reduce_head_kernel(const float* __res
 // Double-DQN target and loss gradient (src/agent.py:97-111):
 //   a* = argmax_a q_next_local[b,a];  target = r + gamma * q_next_target[b,a*] * (1 - done)
 //   loss = mean_b (q[b,action[b]] - target)^2;  dq[b,a] = 2*(q - target)/B on the taken action, else 0
-__global__ void td_loss_kernel(const float* __restrict__ q, const float* __restrict__ q_next_local,
-                               const float* __restrict__ q_next_target, const int64_t* __restrict__ action,
-                               const float* __restrict__ reward, const float* __restrict__ done, float gamma, int B, int NA,
-                               float* __restrict__ dq, float* __restrict__ sq_err) {
+// loss_out != nullptr: the launch is one workgroup that covers the batch (B <= 1024) and also writes the mean of the
+// squared errors, summed in the order of mean_kernel.
+__global__ __launch_bounds__(1024) void td_loss_kernel(const float* __restrict__ q, const float* __restrict__ q_next_local,
+                                                       const float* __restrict__ q_next_target,
+                                                       const int64_t* __restrict__ action, const float* __restrict__ reward,
+                                                       const float* __restrict__ done, float gamma, int B, int NA,
+                                                       float* __restrict__ dq, float* __restrict__ sq_err,
+                                                       float* __restrict__ loss_out) {
+  __shared__ float s_sq[1024];
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  int astar = 0;                                   // the first maximum
-  for (int a = 1; a < NA; a++)
-    if (q_next_local[b * NA + a] > q_next_local[b * NA + astar]) astar = a;
-  const float target = reward[b] + (gamma * q_next_target[b * NA + astar]) * (1.f - done[b]);
-  const int a = (int)min(max(action[b], (int64_t)0), (int64_t)(NA - 1));   // a bad index must not leave the row
-  const float diff = q[b * NA + a] - target;
-  sq_err[b] = diff * diff;
-  for (int k = 0; k < NA; k++) dq[b * NA + k] = k == a ? 2.f * diff / (float)B : 0.f;
+  if (b < B) {
+    int astar = 0;                                   // the first maximum
+    for (int a = 1; a < NA; a++)
+      if (q_next_local[b * NA + a] > q_next_local[b * NA + astar]) astar = a;
+    const float target = reward[b] + (gamma * q_next_target[b * NA + astar]) * (1.f - done[b]);
+    const int a = (int)min(max(action[b], (int64_t)0), (int64_t)(NA - 1));   // a bad index must not leave the row
+    const float diff = q[b * NA + a] - target;
+    sq_err[b] = diff * diff;
+    if (loss_out) s_sq[threadIdx.x] = diff * diff;
+    for (int k = 0; k < NA; k++) dq[b * NA + k] = k == a ? 2.f * diff / (float)B : 0.f;
+  }
+  if (!loss_out) return;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < B; i += 64) s += s_sq[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) *loss_out = s / (float)B;
+  }
 }
 
 // The reference's target without double DQN (src/agent.py:103-105).  Its Q_targets_next keeps a trailing axis
@@ -1747,13 +1766,19 @@ static int learn_dense_half(const float* local, const float* target, const float
     rc = dqn_forward_impl(target, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, NA, w.x1t, w.hidt, w.part, w.qt,
                           stream);
   if (rc) return rc;
-  if (double_dqn)
+  bool mean_done = false;
+  if (double_dqn && B <= 1024) {
+    hipLaunchKernelGGL(flm::td_loss_kernel, dim3(1), dim3(1024), 0, stream, w.q, w.qn, w.qt, action, reward, done, gamma, B,
+                       NA, w.dq, w.sq, loss_out);
+    mean_done = true;
+  } else if (double_dqn) {
     hipLaunchKernelGGL(flm::td_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, w.q, w.qn, w.qt, action, reward, done,
-                       gamma, B, NA, w.dq, w.sq);
-  else
+                       gamma, B, NA, w.dq, w.sq, (float*)nullptr);
+  } else {
     hipLaunchKernelGGL(flm::td_loss_plain_kernel, dim3(1), dim3(1024), 0, stream, w.q, w.qt, action, reward, done, gamma, B,
                        NA, w.dq, w.sq);
-  hipLaunchKernelGGL(flm::mean_kernel, dim3(1), dim3(64), 0, stream, w.sq, B, loss_out);
+  }
+  if (!mean_done) hipLaunchKernelGGL(flm::mean_kernel, dim3(1), dim3(64), 0, stream, w.sq, B, loss_out);
   // head
   hipLaunchKernelGGL(flm::head_backward_hidden_kernel, dim3(B), dim3(64), 0, stream, w.hid, w.dq, local + L.a2_w,
                      local + L.v2_w, B, NA, w.dhid, w.dadv, w.dval);
@@ -1767,9 +1792,8 @@ static int learn_dense_half(const float* local, const float* target, const float
   g.M = 512; g.N = (int)L.K1; g.K = B; g.lda = 1024; g.ldb = L.K1; g.ldc = L.K1;
   g.ksplit = B; g.groups = 2; g.a_zs = 512; g.b_zs = 0; g.c_zs = 0; g.c_gs = L.v1_w - L.a1_w; g.x_slowest = 1;
   if ((rc = flm::launch_gemm<false, false, flm::EPI_PLAIN>(g, 2, stream))) return rc;
-  for (int st = 0; st < 2; st++)
-    hipLaunchKernelGGL(flm::colsum_kernel, dim3(8), dim3(1024), 0, stream, w.dhid + st * 512, B, 512, 1024L,
-                       grads + (st ? L.v1_b : L.a1_b));
+  hipLaunchKernelGGL(flm::colsum_kernel, dim3(16), dim3(1024), 0, stream, w.dhid, B, 1024, 1024L, grads + L.a1_b, 512,
+                     grads + L.v1_b);
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
 }
