@@ -191,9 +191,8 @@ class ReplayBuffer:
     device memory: add() uploads one transition (states as float32 [height*width]), sample() draws batch_size of
     them without replacement and returns the reference's five tensors (states and next states [B,1,height,width]
     float, actions long, rewards and dones float) on the device, as fresh tensors the caller may keep (the
-    reference stacks new tensors per call, src/agent.py:163-172).  One visible difference: the sampled transitions
-    come back in ring order, not in random.sample's order; the loss and its gradients do not depend on the order
-    of a batch."""
+    reference stacks new tensors per call, src/agent.py:163-172), in the sampler's random order as random.sample
+    returns them in its own."""
 
     def __init__(self, action_space, buffer_size, batch_size, width, height):
         self.action_space = action_space

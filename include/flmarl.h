@@ -454,9 +454,9 @@ int flm_dqn_learn_grads_u8_phase(const float* local, const float* target, const 
 /* Uniform sampling without replacement from a replay memory that lives in device memory, and the gather of the
  * sampled transitions.  Replaces ReplayBuffer.sample, src/agent.py:159-174 (random.sample over the deque, then
  * one stacked tensor per field).
- *   flm_replay_sample  idx [batch] int32 out: `batch` distinct entries of 0..size-1, every subset equally likely
- *                      (the entries with the smallest keys hash(seed, draw, entry), listed in index order;
- *                      give every call its own `draw`).  batch <= size.
+ *   flm_replay_sample  idx [batch] int32 out: `batch` distinct entries of 0..size-1 in random order: the images of
+ *                      0..batch-1 under a pseudo-random permutation of the entries keyed by (seed, draw) - give
+ *                      every call its own `draw`.  batch <= size.
  *   flm_replay_gather  rows idx[b] of state / next_state (row_bytes bytes each, a multiple of 16, 16-byte aligned
  *                      bases) and of action int64 / reward float / done float -> the out_* arrays, row b. */
 int flm_replay_sample(int size, int batch, uint32_t seed, uint32_t draw, int32_t* idx, void* stream);

@@ -421,7 +421,6 @@ def test_replay_sampling_kernel():
     for k in range(draws):
         idx = rp.sample_indices(B).cpu().numpy()
         assert len(np.unique(idx)) == B and idx.min() >= 0 and idx.max() < n            # without replacement
-        assert np.all(np.diff(idx) > 0)                                                  # listed in index order
         counts[idx] += 1
         seen.add(idx.tobytes())
     assert len(seen) == draws                                                            # every draw differs
