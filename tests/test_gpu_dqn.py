@@ -593,3 +593,84 @@ def test_learn_step_with_next_states_behind_the_states_gives_the_same_bits(u8):
     assert both[B:].data_ptr() == both.data_ptr() + B * both[0].numel() * both.element_size()
     assert torch.equal(got, want) and torch.equal(loss_g, loss_w)
     assert float(want.abs().max()) > 0
+
+
+@pytest.mark.parametrize("B,Rp,T1", [(64, 20, 37), (130, 3, 151), (96, 12, 96)])
+def test_gradient_error_against_float64_is_of_pytorch_fp32_size(B, Rp, T1):
+    """The gradients of a learn step from float states and from uint8 observations (where the convolution's weight
+    gradient comes from the bytes) against the same step in float64: per parameter tensor the largest error stays within
+    four times the largest error of plain PyTorch fp32 on the same inputs plus 5e-7 of the tensor's largest gradient
+    (four fp32 roundings of it: where PyTorch's own sum happens to come out almost exact, a multiple of its error is no measure).
+    The operand split of the matrix kernels therefore loses nothing that an fp32 implementation keeps."""
+    from flatland_marl_amd.agent import DQNAgent
+    from flatland_marl_amd._lib import call, ptr, query
+    from tests.torch_ref_dqn import TorchDuelingDQN
+    import torch.nn.functional as F
+    H3 = 3 * Rp
+    ps = (Rp * T1 + 255) // 256 * 256
+    torch.manual_seed(31 + B)
+    args = argparse.Namespace(prediction_depth=T1 - 1, lr=0.001, buffer_size=10, batch_size=B, update_every=1,
+                              gamma=0.9, tau=0.05)
+    agent = DQNAgent(args, action_space=2, bitmap_height=H3)
+    # weights spread over a few orders of magnitude, as training leaves them
+    with torch.no_grad():
+        flat = agent.qnetwork_local.flat_params()
+        flat.mul_(torch.exp(2.0 * torch.randn(flat.shape, generator=torch.Generator().manual_seed(1))).to(flat.device))
+    ref32 = TorchDuelingDQN(T1, H3)
+    ref32.load_state_dict(agent.qnetwork_local.state_dict())
+    tgt32 = copy.deepcopy(ref32)
+    with torch.no_grad():
+        for p in tgt32.parameters():
+            p.mul_(0.9)
+    agent.qnetwork_target.load_state_dict(tgt32.state_dict())
+    ref64, tgt64 = copy.deepcopy(ref32).double(), copy.deepcopy(tgt32).double()
+    g = torch.Generator().manual_seed(B)
+    obs = torch.zeros((2, B, 3, ps), dtype=torch.uint8)
+    obs[:, :, 0, :Rp * T1] = torch.randint(-1, 2, (2, B, Rp * T1), generator=g).to(torch.int8).view(torch.uint8)
+    obs[:, :, 1:, :Rp * T1] = torch.randint(0, 12, (2, B, 2, Rp * T1), generator=g).to(torch.uint8)
+    x = torch.cat([obs[:, :, 0, :Rp * T1].view(torch.int8).float(), obs[:, :, 1, :Rp * T1].float(),
+                   obs[:, :, 2, :Rp * T1].float()], dim=2).view(2, B, 1, H3, T1)
+    a = torch.randint(0, 2, (B,), generator=g)
+    r = torch.randn(B, generator=g)
+    d = (torch.rand(B, generator=g) < 0.3).float()
+
+    def grads_of(local, target, s, sn, rr, dd):
+        q = local(s).gather(1, a.unsqueeze(-1)).squeeze(-1)
+        best = local(sn).max(1)[1]
+        q_next = target(sn).gather(1, best.unsqueeze(-1)).squeeze(-1).detach()
+        loss = F.mse_loss(q, rr + 0.9 * q_next * (1 - dd))
+        local.zero_grad()
+        loss.backward()
+        return [p.grad.reshape(-1).double().numpy() for p in local.parameters()]
+
+    g64 = grads_of(ref64, tgt64, x[0].double(), x[1].double(), r.double(), d.double())
+    g32 = grads_of(ref32, tgt32, x[0], x[1], r, d)
+    # the same action choice in both precisions, or the comparison is between two different losses
+    assert torch.equal(ref64(x[1].double()).max(1)[1], ref32(x[1]).max(1)[1])
+    dev = "cuda"
+    local, target = agent.qnetwork_local.flat_params(), agent.qnetwork_target.flat_params()
+    st = torch.cuda.current_stream().cuda_stream
+    out = torch.zeros((2, local.numel()), device=dev)
+    loss = torch.zeros((2, 1), device=dev)
+    ws = torch.empty(query("flm_dqn_learn_workspace_u8", B, Rp, T1, 2), device=dev)
+    xs = x.to(dev).view(2, B, H3, T1).contiguous()
+    o8 = obs.to(dev)
+    ad, rd, dd = a.to(dev), r.to(dev), d.to(dev)
+    call("flm_dqn_learn_grads", ptr(local), ptr(target), ptr(xs[0]), ptr(xs[1]), ptr(ad), ptr(rd), ptr(dd), 0.9, 1, B, H3, T1,
+         2, ptr(ws), ptr(out[0]), ptr(loss[0]), st)
+    call("flm_dqn_learn_grads_u8", ptr(local), ptr(target), ptr(o8[0]), ptr(o8[1]), ps, ptr(ad), ptr(rd), ptr(dd), 0.9, 1, B,
+         Rp, T1, 2, ptr(ws), ptr(out[1]), ptr(loss[1]), st)
+    torch.cuda.synchronize()
+    got = out.cpu().double().numpy()
+    worst = 0.0
+    for which in range(2):
+        off = 0
+        for w64, w32 in zip(g64, g32):
+            n = w64.size
+            e_ours = np.abs(got[which, off:off + n] - w64).max()
+            e_t32 = np.abs(w32 - w64).max()
+            top = np.abs(w64).max()
+            assert e_ours <= 4.0 * e_t32 + 5e-7 * top, (which, off, e_ours, e_t32, top)
+            worst = max(worst, e_ours / max(e_t32, 1e-30))
+            off += n
+    assert worst > 0
