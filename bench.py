@@ -162,6 +162,9 @@ def rollout_sample(device, steps=40, workload="cfg2g", max_rails=70, rank=0, wor
                     "transitions_per_step": (tr.n_transitions - n0) / steps,
                     "learn_steps_per_step": (tr.n_learn - l0) / steps,
                     "agents_flagged": flagged, "agents_over_capacity": overflowed, "steps_timed": steps}
+        if train and tr.n_learn > l0:
+            # the whole step over its learn steps (how many a step takes moves with what the policy has learnt)
+            out[key]["ms_per_learn_step_incl_rollout"] = dt * 1e3 * steps / (tr.n_learn - l0)
         if train:
             out[key]["learn_cadence"] = {
                 "update_every": a.update_every, "batch_size": a.batch_size, "cap_per_rollout_step": cap,
