@@ -61,6 +61,7 @@ _SIGNATURES = {
     "flm_dqn_forward": [_p, _p, _i, _i, _i, _i, _p, _p, _p],
     "flm_obs_to_f32": [_p, _i, _i, _i, _i, _p, _p],
     "flm_dqn_forward_u8": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
+    "flm_dqn_forward_u8_rails": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     "flm_dqn_learn_grads": [_p, _p, _p, _p, _p, _p, _p, C.c_float, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     "flm_observations_req_columns_rows": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "flm_replay_store": [_p, _i, _p, _i, _p, _p, C.c_long, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],

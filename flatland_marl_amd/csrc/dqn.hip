@@ -66,6 +66,11 @@ struct GemmArgs {
   int x_slowest;       // order in which workgroups are dealt to the XCDs (split-operand kernel): see there
   int b_break_k;       // > 0 (B not k-contiguous only): rows k >= b_break_k of B start b_break_off floats further on
   long b_break_off;    // (two [K/2, N] blocks that are not adjacent in memory multiplied as one [K, N] matrix)
+  // B_SEG kernels (B k-contiguous): the product's k runs over segments of b_seg_len consecutive elements that lie
+  // b_seg_stride apart in B's rows: element k of the product is B[n*ldb + (k / b_seg_len) * b_seg_stride + k % b_seg_len]
+  // (b_seg_len a multiple of 4, K < 65536; b_seg_magic = ceil(2^32 / b_seg_len) turns the division into a multiply)
+  int b_seg_len, b_seg_stride;
+  unsigned b_seg_magic;
 };
 
 #define GBM 128
@@ -106,9 +111,13 @@ __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsign
 // KC (k contiguous): thread (row = tid >> 2, kq = tid & 3); v[half][i] = row, k 16*half + 4*kq + i.
 // otherwise (rows contiguous): thread (rq = tid >> 4, k16 = tid & 15); v[half][i] = k 16*half + k16, row 4*rq + i.
 // FAST: the slice lies inside the matrix and its rows are 16-byte aligned: no test around any load.
-template <bool KC, bool FAST>
+// SEG (KC only): k is mapped through segments (GemmArgs::b_seg_*); the 16-byte loads are then only 4-byte aligned,
+// which global memory allows.
+struct __attribute__((aligned(4))) F4U { float v[4]; };
+template <bool KC, bool FAST, bool SEG = false>
 __device__ __forceinline__ void fetch_x3(const float* __restrict__ P, long ld, int r0, int rmax, int k0, int kmax, bool vec,
-                                         int tid, float (&v)[2][4], int break_k = 0, long break_off = 0) {
+                                         int tid, float (&v)[2][4], int break_k = 0, long break_off = 0, int seg_len = 0,
+                                         int seg_stride = 0, unsigned seg_magic = 0) {
 #pragma unroll
   for (int half = 0; half < 2; half++) {
     int r, k;
@@ -117,7 +126,12 @@ __device__ __forceinline__ void fetch_x3(const float* __restrict__ P, long ld, i
     if (KC) {
       r = r0 + (tid >> 2);
       k = k0 + 16 * half + 4 * (tid & 3);
-      p = P + (long)r * ld + k;
+      if (SEG) {
+        const unsigned sg = __umulhi((unsigned)k, seg_magic);
+        p = P + (long)r * ld + (long)sg * seg_stride + ((unsigned)k - sg * (unsigned)seg_len);
+      } else {
+        p = P + (long)r * ld + k;
+      }
       ok = r < rmax && k + 3 < kmax;
     } else {
       r = r0 + 4 * (tid >> 4);
@@ -125,7 +139,10 @@ __device__ __forceinline__ void fetch_x3(const float* __restrict__ P, long ld, i
       p = P + (long)k * ld + r + ((break_k > 0 && k >= break_k) ? break_off : 0);
       ok = k < kmax && r + 3 < rmax;
     }
-    if (FAST || (vec && ok)) {
+    if (SEG && (FAST || (vec && ok))) {
+      const F4U t = *reinterpret_cast<const F4U*>(p);
+      v[half][0] = t.v[0]; v[half][1] = t.v[1]; v[half][2] = t.v[2]; v[half][3] = t.v[3];
+    } else if (FAST || (vec && ok)) {
       const float4 t = *reinterpret_cast<const float4*>(p);
       v[half][0] = t.x; v[half][1] = t.y; v[half][2] = t.z; v[half][3] = t.w;
     } else {
@@ -194,7 +211,7 @@ __device__ __forceinline__ void stage_schedule() {
   }
 }
 
-template <bool A_KC, bool B_KC, int EPI>
+template <bool A_KC, bool B_KC, int EPI, bool B_SEG = false>
 __global__ __launch_bounds__(512, 4) void gemm_x3_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned x3_lds[];   // [stage][A, B][split][row][XROW]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -224,7 +241,7 @@ __global__ __launch_bounds__(512, 4) void gemm_x3_kernel(GemmArgs g) {
   const int k_begin = slice * g.ksplit;
   const int k_end = g.ksplit ? min(g.K, k_begin + g.ksplit) : g.K;
   const bool a_vec = (g.lda & 3) == 0 && (reinterpret_cast<size_t>(A) & 15) == 0;
-  const bool b_vec = (g.ldb & 3) == 0 && (reinterpret_cast<size_t>(B) & 15) == 0 && (g.b_break_off & 3) == 0;
+  const bool b_vec = B_SEG || ((g.ldb & 3) == 0 && (reinterpret_cast<size_t>(B) & 15) == 0 && (g.b_break_off & 3) == 0);
   f32x16 acc[2];
 #pragma unroll
   for (int i = 0; i < 2; i++)
@@ -268,7 +285,8 @@ __global__ __launch_bounds__(512, 4) void gemm_x3_kernel(GemmArgs g) {
       // past the end the last slice is fetched again (FAST has no tests) and never placed
       const int k0 = k_begin + (FAST ? min(f, nf - 1) : f) * XBK;
       fetch_x3<A_KC, FAST>(A, g.lda, m0, g.M, k0, k_end, a_vec, tid, ra);
-      fetch_x3<B_KC, FAST>(B, g.ldb, n0, g.N, k0, k_end, b_vec, tid, rb, g.b_break_k, g.b_break_off);
+      fetch_x3<B_KC, FAST, B_SEG>(B, g.ldb, n0, g.N, k0, k_end, b_vec, tid, rb, g.b_break_k, g.b_break_off, g.b_seg_len,
+                                  g.b_seg_stride, g.b_seg_magic);
     };
     auto place = [&](int stage, int half, const float (&ra)[2][4], const float (&rb)[2][4]) {
       unsigned* As = x3_lds + stage * 2 * XSTAGE;
@@ -346,12 +364,12 @@ __global__ __launch_bounds__(512, 4) void gemm_x3_kernel(GemmArgs g) {
   }
 }
 
-template <bool A_KC, bool B_KC, int EPI>
+template <bool A_KC, bool B_KC, int EPI, bool B_SEG = false>
 static int launch_gemm(const GemmArgs& g, int nz, hipStream_t stream) {
   dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, nz);
   // the kernel's LDS limit is raised once per device (the attribute belongs to the device's copy of the kernel)
-  FLM_RAISE_LDS_ONCE((gemm_x3_kernel<A_KC, B_KC, EPI>));
-  hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, EPI>), grid, dim3(512), X3_LDS_BYTES, stream, g);
+  FLM_RAISE_LDS_ONCE((gemm_x3_kernel<A_KC, B_KC, EPI, B_SEG>));
+  hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, EPI, B_SEG>), grid, dim3(512), X3_LDS_BYTES, stream, g);
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
 }
@@ -627,6 +645,37 @@ __global__ __launch_bounds__(64) void head_forward_kernel(const float* __restric
     for (int a = 0; a < FLM_DQN_MAX_ACTIONS; a++)
       if (a < NA) q[b * NA + a] = val + sa[a] - mean;
   }
+}
+
+// Rails that no environment has: rows [R4, Rp) of all three planes of every observation are zero, so the convolution
+// gives relu(conv bias) there for every sample, and their share of the first dense layer is the same vector for every
+// sample: bias2[o] = bias[o] + sum over filters c, planes and rails >= R4 of relu(conv_b[c]) * W[o][c*H3 + plane*Rp + rail].
+// One workgroup per output unit o (advantage stream first), one thread per (filter, plane), sums combined in a fixed order.
+__global__ __launch_bounds__(256) void fc1_padding_bias_kernel(const float* __restrict__ Wa, const float* __restrict__ Wv,
+                                                               const float* __restrict__ bias_a, const float* __restrict__ bias_v,
+                                                               const float* __restrict__ conv_b, long K1, int H3, int Rp, int R4,
+                                                               float* __restrict__ bias2) {
+  __shared__ float red[256];
+  const int o = blockIdx.x, t = threadIdx.x;
+  const float* W = o < 512 ? Wa + (long)o * K1 : Wv + (long)(o - 512) * K1;
+  float acc = 0.f;
+  if (t < 192) {
+    const int c = t / 3, pl = t - 3 * c;
+    const float r = fmaxf(conv_b[c], 0.f);
+    if (r > 0.f) {
+      const float* w = W + (long)c * H3 + (long)pl * Rp;
+      float a = 0.f;
+      for (int rail = R4; rail < Rp; rail++) a += w[rail];
+      acc = r * a;
+    }
+  }
+  red[t] = acc;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (t < st) red[t] += red[t + st];
+    __syncthreads();
+  }
+  if (t == 0) bias2[o] = (o < 512 ? bias_a[o] : bias_v[o - 512]) + red[0];
 }
 
 // The split-K reduction of the first dense layer (both streams) with its bias and ReLU, then the output layers and
@@ -1513,7 +1562,7 @@ extern "C" long flm_dqn_param_count(int H3, int T1, int NA) { return actions_ok(
 
 // workspace floats needed by flm_dqn_forward for a batch of B samples
 extern "C" long flm_dqn_forward_workspace(int B, int H3) {
-  return (long)B * 64 * H3 + (long)B * 1024 + (long)fc1_k_slices(B) * B * 1024;
+  return (long)B * 64 * H3 + (long)B * 1024 + (long)fc1_k_slices(B) * B * 1024 + 1024;   // x1, hid, K slices, a bias vector
 }
 
 // small batches (act): the first dense layer streams both weight matrices in one launch
@@ -1642,6 +1691,52 @@ static int dqn_forward_impl(const float* params, const float* x, const uint8_t* 
   return rc ? rc : dqn_dense_stage(params, B, H3, T1, NA, x1, hid, part, q, stream);
 }
 
+// rails actually used by the observations, rounded up to whole groups of four; 0 = the padded rows are too few to be
+// worth a pass of their own, the batch is one of the small ones that stream the weights, or the indices do not fit
+static int dqn_rails_used(int B, int Rp, int rails_used) {
+  if (rails_used <= 0 || B <= 8) return 0;
+  const int R4 = (rails_used + 3) & ~3;
+  if (R4 + 4 > Rp || 192L * R4 >= 65536) return 0;
+  return R4;
+}
+
+// The forward pass from uint8 observations whose rails [R4, Rp) are empty in every plane: the convolution runs over
+// the R4 used rails of each plane only (x1c [B,64,3*R4]), the first dense layer multiplies those columns of its weights
+// (segments of R4 in rows of 3*Rp per filter) and the empty rails enter through the bias (fc1_padding_bias_kernel).
+// bias2: 1024 floats of workspace.
+static int dqn_forward_rails(const float* params, const uint8_t* obs_u8, int plane_stride, int B, int Rp, int R4, int T1,
+                             int NA, float* x1c, float* hid, float* part, float* bias2, float* q, hipStream_t stream) {
+  const int H3 = 3 * Rp;
+  DqnLayout L(H3, T1, NA);
+  // the byte convolution addresses a row as (sample, plane, rail) with plane_stride bytes between planes: with R4 rails
+  // per plane instead of Rp it reads the used rails and writes the compact activations
+  int rc = dqn_conv_stage(params, nullptr, obs_u8, plane_stride, B, 3 * R4, T1, NA, x1c, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(flm::fc1_padding_bias_kernel, dim3(1024), dim3(256), 0, stream, params + L.a1_w, params + L.v1_w,
+                     params + L.a1_b, params + L.v1_b, params + L.conv_b, L.K1, H3, Rp, R4, bias2);
+  const long Kc = 192L * R4;
+  const int nks = fc1_k_slices(B);
+  const int ks = (int)(((Kc + nks - 1) / nks + XBK - 1) / XBK * XBK);
+  GemmArgs g{};
+  g.A = x1c; g.B = params + L.a1_w; g.C = part;
+  g.M = B; g.N = 512; g.K = (int)Kc; g.lda = Kc; g.ldb = L.K1; g.ldc = 1024;
+  g.a_zs = 0; g.b_zs = L.v1_w - L.a1_w; g.c_zs = (long)B * 1024; g.c_gs = 512; g.groups = 2; g.ksplit = ks;
+  g.b_seg_len = R4; g.b_seg_stride = Rp; g.b_seg_magic = (unsigned)((0x100000000ULL + (unsigned)R4 - 1) / (unsigned)R4);
+  if ((rc = flm::launch_gemm<true, true, flm::EPI_PLAIN, true>(g, 2 * nks, stream))) return rc;
+  if ((((uintptr_t)part | (uintptr_t)hid | (uintptr_t)bias2) & 15) == 0) {
+    hipLaunchKernelGGL(flm::fc1_reduce_head_kernel, dim3(B), dim3(256), 0, stream, part, nks, B, bias2, bias2 + 512, hid,
+                       params + L.a2_w, params + L.a2_b, params + L.v2_w, params + L.v2_b, NA, q);
+  } else {
+    const long ne = (long)B * 1024;
+    hipLaunchKernelGGL(flm::reduce_bias_relu_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream, part, nks, B,
+                       1024, bias2, bias2 + 512, 512, hid, 1024L);
+    hipLaunchKernelGGL(flm::head_forward_kernel, dim3(B), dim3(64), 0, stream, hid, params + L.a2_w, params + L.a2_b,
+                       params + L.v2_w, params + L.v2_b, B, NA, q);
+  }
+  if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
+  return FLM_OK;
+}
+
 extern "C" int flm_dqn_forward(const float* params, const float* x, int B, int H3, int T1, int NA, float* workspace,
                                float* q, void* stream) {
   if (!params || !x || !workspace || !q || B <= 0 || H3 <= 0 || T1 <= 0 || !actions_ok(NA)) return FLM_E_ARG;
@@ -1661,6 +1756,21 @@ extern "C" int flm_dqn_forward_u8(const float* params, const uint8_t* obs, int n
   float* hid = workspace + (long)n * 64 * H3;
   float* part = hid + (long)n * 1024;
   return dqn_forward_impl(params, nullptr, obs, plane_stride, n, H3, T1, NA, x1, hid, part, q, (hipStream_t)stream);
+}
+
+extern "C" int flm_dqn_forward_u8_rails(const float* params, const uint8_t* obs, int n, int Rp, int T1, int plane_stride,
+                                        int NA, int rails_used, float* workspace, float* q, void* stream) {
+  if (!params || !obs || !workspace || !q || n <= 0 || Rp <= 0 || T1 <= 0 || (long)plane_stride < (long)Rp * T1 ||
+      !actions_ok(NA) || rails_used < 0 || rails_used > Rp)
+    return FLM_E_ARG;
+  const int R4 = dqn_rails_used(n, Rp, rails_used);
+  if (!R4) return flm_dqn_forward_u8(params, obs, n, Rp, T1, plane_stride, NA, workspace, q, stream);
+  const int H3 = 3 * Rp;
+  float* x1c = workspace;                                   // (the layout of flm_dqn_forward_u8: the compact x1 is smaller)
+  float* hid = workspace + (long)n * 64 * H3;
+  float* part = hid + (long)n * 1024;
+  float* bias2 = part + (long)fc1_k_slices(n) * n * 1024;
+  return dqn_forward_rails(params, obs, plane_stride, n, Rp, R4, T1, NA, x1c, hid, part, bias2, q, (hipStream_t)stream);
 }
 
 extern "C" int flm_obs_to_f32(const uint8_t* obs, int n, int Rp, int T1, int plane_stride, float* out, void* stream) {

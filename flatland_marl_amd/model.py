@@ -87,16 +87,19 @@ class Dueling_DQN(nn.Module):
              torch.cuda.current_stream(flat.device).cuda_stream)
         return q
 
-    def forward_obs(self, obs_u8, plane_stride):
+    def forward_obs(self, obs_u8, plane_stride, rails_used=0):
         """Q-values [n,action_space] straight from uint8 observations [n,3,plane_stride] (plane 0 int8, heat planes uint8,
-        rows of `width` bytes): the convolution reads the bytes, no float copy of the input is made."""
+        rows of `width` bytes): the convolution reads the bytes, no float copy of the input is made.
+        rails_used > 0: the caller vouches that rails rails_used.. of every plane are empty (the padding up to
+        max_rails); they are then not computed but enter through the first dense layer's bias."""
         flat = self.flat_params()
         if self.height % 3:
             raise ValueError("observations have three planes: the network height must be 3*max_rails")
         obs_u8 = obs_u8.contiguous()
         n = obs_u8.size(0)
         q = torch.empty((n, self.action_space), dtype=torch.float32, device=flat.device)
-        call("flm_dqn_forward_u8", ptr(flat), ptr(obs_u8), n, self.height // 3, self.width, int(plane_stride),
-             self.action_space, ptr(self._workspace(n)), ptr(q), torch.cuda.current_stream(flat.device).cuda_stream)
+        call("flm_dqn_forward_u8_rails", ptr(flat), ptr(obs_u8), n, self.height // 3, self.width, int(plane_stride),
+             self.action_space, int(rails_used), ptr(self._workspace(n)), ptr(q),
+             torch.cuda.current_stream(flat.device).cuda_stream)
         return q
 

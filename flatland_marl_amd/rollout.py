@@ -266,6 +266,11 @@ class RolloutBatch:
         info["net_in"], info["best"] = net_in, best
         return info
 
+    def rails_used(self):
+        """The largest number of rails of any environment of the batch: rows from there on are empty in every plane
+        of every observation (the padding up to max_rails)."""
+        return int(np.asarray(self.b.R).max())
+
     def read_counts(self):
         """[departing agents, agents before a switch, network rows] as the kernels enqueued so far leave them."""
         self._counts_event.record(self.b.stream)

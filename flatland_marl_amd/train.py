@@ -61,12 +61,13 @@ class DQNPolicy:
         per = 64 * 3 * b.Rp * 4                            # the convolution output dominates the workspace
         chunk = max(1, self.chunk_bytes // per)
         net = self.agent.qnetwork_local
+        rails = ro.rails_used()                            # rails beyond these are padding in every observation
         if n <= chunk:
-            return net.forward_obs(obs_u8, b.plane_stride)
+            return net.forward_obs(obs_u8, b.plane_stride, rails)
         q = torch.empty((n, 2), dtype=torch.float32, device=obs_u8.device)
         for lo in range(0, n, chunk):
             hi = min(n, lo + chunk)
-            q[lo:hi] = net.forward_obs(obs_u8[lo:hi], b.plane_stride)
+            q[lo:hi] = net.forward_obs(obs_u8[lo:hi], b.plane_stride, rails)
         return q
 
     def __call__(self, ro, info):

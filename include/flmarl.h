@@ -410,6 +410,16 @@ int flm_dqn_forward(const float* params, const float* x, int B, int H3, int T1, 
 int flm_dqn_forward_u8(const float* params, const uint8_t* obs, int n, int Rp, int T1, int plane_stride, int NA,
                        float* workspace, float* q, void* stream);
 
+/* flm_dqn_forward_u8 for observations whose rails [rails_used, Rp) are empty in every plane (the padding of
+ * src/preprocessing.py:36-50 up to max_rails: an environment with R rails fills rows 0..R-1 of each plane only).
+ * The empty rows leave the convolution as relu(bias) for every sample, so their share of the first dense layer
+ * (src/model.py:33-41) is one vector per set of weights: it is added to the layer's bias, and the convolution and the
+ * layer's product run over the used rails only.  Same Q-values as flm_dqn_forward_u8 up to fp32 rounding (the sums are
+ * taken in another order).  rails_used = 0, rails_used > Rp - 8 or n <= 8: the plain form runs.  The caller vouches
+ * for the empty rows: what they hold is not read.  Workspace as flm_dqn_forward_u8. */
+int flm_dqn_forward_u8_rails(const float* params, const uint8_t* obs, int n, int Rp, int T1, int plane_stride, int NA,
+                             int rails_used, float* workspace, float* q, void* stream);
+
 /* uint8 observations [n,3,plane_stride] (own plane int8) -> float rows [n,3*Rp,T1], the network's input. */
 int flm_obs_to_f32(const uint8_t* obs, int n, int Rp, int T1, int plane_stride, float* out, void* stream);
 

@@ -674,3 +674,42 @@ def test_gradient_error_against_float64_is_of_pytorch_fp32_size(B, Rp, T1):
             worst = max(worst, e_ours / max(e_t32, 1e-30))
             off += n
     assert worst > 0
+
+
+@pytest.mark.parametrize("Rp,T1,B,rails", [(70, 151, 300, 17), (100, 151, 64, 14), (70, 151, 2250, 9), (23, 61, 40, 5),
+                                           (70, 151, 33, 61), (70, 151, 33, 64), (16, 37, 20, 8), (70, 151, 5, 17)])
+def test_forward_over_the_used_rails_matches_the_plain_forward(Rp, T1, B, rails):
+    """flm_dqn_forward_u8_rails (rails from `rails` on are empty in every plane: they are not computed but enter through
+    the first dense layer's bias) against flm_dqn_forward_u8 on the same observations: Q-values within 1e-5 per element
+    (close_q).  Rail counts that are and are not multiples of four, too few empty rails to bother (the plain form runs),
+    a small batch (plain form), weights with conv biases of both signs so that relu(bias) is zero for some filters."""
+    import types
+    from flatland_marl_amd.agent import DQNAgent
+    ps = (Rp * T1 + 255) // 256 * 256
+    args = types.SimpleNamespace(prediction_depth=T1 - 1, lr=5e-5, buffer_size=10, batch_size=B, update_every=10,
+                                 gamma=0.99, tau=1e-3)
+    torch.manual_seed(3)
+    agent = DQNAgent(args, action_space=2, bitmap_height=3 * Rp)
+    net = agent.qnetwork_local
+    with torch.no_grad():                                      # weights as training leaves them: spread, biases of both signs
+        flat = net.flat_params()
+        flat.mul_(torch.exp(torch.randn(flat.shape, generator=torch.Generator().manual_seed(1))).to(flat.device))
+        sd = net.state_dict()
+        assert (sd["conv1.bias"] > 0).any() and (sd["conv1.bias"] < 0).any()
+    g = torch.Generator().manual_seed(B)
+    obs = torch.zeros((B, 3, Rp, T1), dtype=torch.uint8)
+    obs[:, 0, :rails] = torch.randint(-1, 2, (B, rails, T1), generator=g).to(torch.int8).view(torch.uint8)
+    obs[:, 1:, :rails] = torch.randint(0, 30, (B, 2, rails, T1), generator=g).to(torch.uint8)
+    buf = torch.full((B, 3, ps), 91, dtype=torch.uint8)       # bytes between the planes must not matter
+    buf[:, :, :Rp * T1] = obs.view(B, 3, Rp * T1)
+    buf = buf.cuda()
+    want = net.forward_obs(buf, ps).cpu().numpy()
+    got = net.forward_obs(buf, ps, rails_used=rails).cpu().numpy()
+    assert close_q(got, want)
+    assert np.abs(want).max() > 0
+    # what the empty rows hold is not read: garbage there leaves the result of the rails form unchanged
+    buf2 = buf.clone()
+    buf2.view(B, 3, ps)[:, :, ((rails + 3) & ~3) * T1:Rp * T1] = 201
+    if ((rails + 3) & ~3) + 4 <= Rp and B > 8:
+        got2 = net.forward_obs(buf2, ps, rails_used=rails).cpu().numpy()
+        assert np.array_equal(got2, got)
