@@ -58,6 +58,7 @@ _SIGNATURES = {
     "flm_dqn_grad_split": [_i, _i, _i],
     "flm_dqn_learn_grads_phase": [_p, _p, _p, _p, _p, _p, _p, C.c_float, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p],
     "flm_dqn_learn_grads_u8_phase": [_p, _p, _p, _p, _i, _p, _p, _p, C.c_float, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p],
+    "flm_dqn_learn_grads_u8_rails": [_p, _p, _p, _p, _i, _p, _p, _p, C.c_float, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p],
     "flm_dqn_forward": [_p, _p, _i, _i, _i, _i, _p, _p, _p],
     "flm_obs_to_f32": [_p, _i, _i, _i, _i, _p, _p],
     "flm_dqn_forward_u8": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p],

@@ -125,9 +125,11 @@ class DQNAgent:
         self.last_loss = loss
         self._update(target)
 
-    def learn_obs(self, experiences, gamma, plane_stride):
+    def learn_obs(self, experiences, gamma, plane_stride, rails_used=0):
         """learn() on uint8 observations [B,3,plane_stride] (plane 0 int8, heat planes uint8) as a device replay
-        memory stores them: same update, no float copies of the next states."""
+        memory stores them: same update, no float copies of the next states.  rails_used > 0: the caller vouches that
+        rails rails_used.. of every plane of every observation are empty (the padding up to max_rails); the step
+        then computes over the used rails and adds what the empty ones contribute in closed form."""
         states, actions, rewards, next_states, dones = experiences
         B = states.size(0)
         if self.height % 3:
@@ -149,26 +151,29 @@ class DQNAgent:
         self.optimizer._ensure()                            # (no zero_grad: the kernels write every gradient element)
         st = torch.cuda.current_stream(dev).cuda_stream
         args = (ptr(local), ptr(target), ptr(s), ptr(sn), int(plane_stride), ptr(a), ptr(r), ptr(d),
-                float(gamma), 1 if self.double_dqn else 0, B, Rp, self.width, self.action_space, ptr(self._ws),
-                ptr(self.optimizer.grads), ptr(loss))
-        self._grads_and_exchange("flm_dqn_learn_grads_u8", args, st)
+                float(gamma), 1 if self.double_dqn else 0, B, Rp, self.width, self.action_space, int(rails_used),
+                ptr(self._ws), ptr(self.optimizer.grads), ptr(loss))
+        self._grads_and_exchange("flm_dqn_learn_grads_u8_rails", args, st, phased_entry=True)
         self.last_loss = loss
         self._update(target)
 
-    def _grads_and_exchange(self, entry, args, stream):
+    def _grads_and_exchange(self, entry, args, stream, phased_entry=False):
         """The gradients of one learn step and, with several ranks, their average over the ranks (the reference is a
         single process, src/agent.py:14: one rank is its algorithm).  Data parallel: the step runs in two halves;
         the gradients of the dense layers (98 % of the flat buffer) are final after the first and travel while the
-        second computes the convolution's, whose small sum follows; both are waited for before the optimizer."""
+        second computes the convolution's, whose small sum follows; both are waited for before the optimizer.
+        phased_entry: the entry point itself takes the phase (0 = the whole step) in front of the stream."""
+        whole = (lambda: call(entry, *args, 0, stream)) if phased_entry else (lambda: call(entry, *args, stream))
+        half = (lambda ph: call(entry, *args, ph, stream)) if phased_entry else (lambda ph: call(entry + "_phase", *args, ph, stream))
         if not parallel.distributed():
-            call(entry, *args, stream)
+            whole()
             return
         grads = self.optimizer.grads
         split = query("flm_dqn_grad_split", self.height, self.width, self.action_space)
         ex = self.exchange = parallel.GradientExchange()
-        call(entry + "_phase", *args, 1, stream)
+        half(1)
         ex.begin(grads[split:])
-        call(entry + "_phase", *args, 2, stream)
+        half(2)
         ex.begin(grads[:split])
         ex.finish()
 

@@ -66,9 +66,11 @@ struct GemmArgs {
   int x_slowest;       // order in which workgroups are dealt to the XCDs (split-operand kernel): see there
   int b_break_k;       // > 0 (B not k-contiguous only): rows k >= b_break_k of B start b_break_off floats further on
   long b_break_off;    // (two [K/2, N] blocks that are not adjacent in memory multiplied as one [K, N] matrix)
-  // B_SEG kernels (B k-contiguous): the product's k runs over segments of b_seg_len consecutive elements that lie
-  // b_seg_stride apart in B's rows: element k of the product is B[n*ldb + (k / b_seg_len) * b_seg_stride + k % b_seg_len]
-  // (b_seg_len a multiple of 4, K < 65536; b_seg_magic = ceil(2^32 / b_seg_len) turns the division into a multiply)
+  // Segment mapping (kernels with SEG != 0): an index i of the product stands for element
+  // seg(i) = (i / b_seg_len) * b_seg_stride + i % b_seg_len of a wider row in memory (b_seg_len a multiple of 4, the
+  // index range below 65536; b_seg_magic = ceil(2^32 / b_seg_len) turns the division into a multiply).  SEG 1: the k of
+  // a k-contiguous B, B[n*ldb + seg(k)]; SEG 2: the n of a row-contiguous B, B[k*ldb + seg(n)]; SEG 3: the n of C,
+  // C[m*ldc + seg(n)] (plain epilogue).
   int b_seg_len, b_seg_stride;
   unsigned b_seg_magic;
 };
@@ -111,8 +113,8 @@ __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsign
 // KC (k contiguous): thread (row = tid >> 2, kq = tid & 3); v[half][i] = row, k 16*half + 4*kq + i.
 // otherwise (rows contiguous): thread (rq = tid >> 4, k16 = tid & 15); v[half][i] = k 16*half + k16, row 4*rq + i.
 // FAST: the slice lies inside the matrix and its rows are 16-byte aligned: no test around any load.
-// SEG (KC only): k is mapped through segments (GemmArgs::b_seg_*); the 16-byte loads are then only 4-byte aligned,
-// which global memory allows.
+// SEG: the operand's contiguous axis (k when KC, the rows otherwise) is mapped through segments (GemmArgs::b_seg_*);
+// the 16-byte loads are then only 4-byte aligned, which global memory allows.
 struct __attribute__((aligned(4))) F4U { float v[4]; };
 template <bool KC, bool FAST, bool SEG = false>
 __device__ __forceinline__ void fetch_x3(const float* __restrict__ P, long ld, int r0, int rmax, int k0, int kmax, bool vec,
@@ -136,7 +138,12 @@ __device__ __forceinline__ void fetch_x3(const float* __restrict__ P, long ld, i
     } else {
       r = r0 + 4 * (tid >> 4);
       k = k0 + 16 * half + (tid & 15);
-      p = P + (long)k * ld + r + ((break_k > 0 && k >= break_k) ? break_off : 0);
+      long rr = r;
+      if (SEG) {                      // the rows of this operand are the mapped axis (four consecutive ones stay together)
+        const unsigned sg = __umulhi((unsigned)r, seg_magic);
+        rr = (long)sg * seg_stride + ((unsigned)r - sg * (unsigned)seg_len);
+      }
+      p = P + (long)k * ld + rr + ((break_k > 0 && k >= break_k) ? break_off : 0);
       ok = k < kmax && r + 3 < rmax;
     }
     if (SEG && (FAST || (vec && ok))) {
@@ -211,8 +218,10 @@ __device__ __forceinline__ void stage_schedule() {
   }
 }
 
-template <bool A_KC, bool B_KC, int EPI, bool B_SEG = false>
+template <bool A_KC, bool B_KC, int EPI, int SEG = 0>
 __global__ __launch_bounds__(512, 4) void gemm_x3_kernel(GemmArgs g) {
+  constexpr bool B_SEG = SEG == 1 || SEG == 2;
+  static_assert(SEG == 0 || (SEG == 1 && B_KC) || (SEG == 2 && !B_KC) || (SEG == 3 && EPI == EPI_PLAIN), "segment mapping");
   extern __shared__ __attribute__((aligned(16))) unsigned x3_lds[];   // [stage][A, B][split][row][XROW]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;                 // 8 waves as 2 x 4, each 2 x 1 tiles of 32 x 32
@@ -352,6 +361,9 @@ __global__ __launch_bounds__(512, 4) void gemm_x3_kernel(GemmArgs g) {
           if (EPI == EPI_CONV) {
             const int b = m / g.H3, h = m - b * g.H3;
             idx = ((long)b * g.N + n) * g.H3 + h;
+          } else if (SEG == 3) {
+            const unsigned sg = __umulhi((unsigned)n, g.b_seg_magic);
+            idx = (long)m * g.ldc + (long)sg * g.b_seg_stride + ((unsigned)n - sg * (unsigned)g.b_seg_len);
           } else {
             idx = (long)m * g.ldc + n;
           }
@@ -364,12 +376,12 @@ __global__ __launch_bounds__(512, 4) void gemm_x3_kernel(GemmArgs g) {
   }
 }
 
-template <bool A_KC, bool B_KC, int EPI, bool B_SEG = false>
+template <bool A_KC, bool B_KC, int EPI, int SEG = 0>
 static int launch_gemm(const GemmArgs& g, int nz, hipStream_t stream) {
   dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, nz);
   // the kernel's LDS limit is raised once per device (the attribute belongs to the device's copy of the kernel)
-  FLM_RAISE_LDS_ONCE((gemm_x3_kernel<A_KC, B_KC, EPI, B_SEG>));
-  hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, EPI, B_SEG>), grid, dim3(512), X3_LDS_BYTES, stream, g);
+  FLM_RAISE_LDS_ONCE((gemm_x3_kernel<A_KC, B_KC, EPI, SEG>));
+  hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, EPI, SEG>), grid, dim3(512), X3_LDS_BYTES, stream, g);
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
 }
@@ -649,33 +661,40 @@ __global__ __launch_bounds__(64) void head_forward_kernel(const float* __restric
 
 // Rails that no environment has: rows [R4, Rp) of all three planes of every observation are zero, so the convolution
 // gives relu(conv bias) there for every sample, and their share of the first dense layer is the same vector for every
-// sample: bias2[o] = bias[o] + sum over filters c, planes and rails >= R4 of relu(conv_b[c]) * W[o][c*H3 + plane*Rp + rail].
-// One workgroup per output unit o (advantage stream first), one thread per (filter, plane), sums combined in a fixed order.
+// sample: bias2[o] = bias[o] + sum over filters c of relu(conv_b[c]) * wpad[o][c], where wpad[o][c] is the sum of
+// W[o][c*H3 + plane*Rp + rail] over the planes and the rails >= R4.  One workgroup per output unit o (advantage stream
+// first); a wave takes every fourth (filter, plane) segment, its lanes the segment's consecutive weights; all sums
+// in a fixed order.  wpad_out (optional): wpad[1024][64], which the backward pass needs as well.
 __global__ __launch_bounds__(256) void fc1_padding_bias_kernel(const float* __restrict__ Wa, const float* __restrict__ Wv,
                                                                const float* __restrict__ bias_a, const float* __restrict__ bias_v,
                                                                const float* __restrict__ conv_b, long K1, int H3, int Rp, int R4,
-                                                               float* __restrict__ bias2) {
-  __shared__ float red[256];
-  const int o = blockIdx.x, t = threadIdx.x;
+                                                               float* __restrict__ bias2, float* __restrict__ wpad_out) {
+  __shared__ float seg_sum[192];
+  __shared__ float red[64];
+  const int o = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
   const float* W = o < 512 ? Wa + (long)o * K1 : Wv + (long)(o - 512) * K1;
-  float acc = 0.f;
-  if (t < 192) {
-    const int c = t / 3, pl = t - 3 * c;
-    const float r = fmaxf(conv_b[c], 0.f);
-    if (r > 0.f) {
-      const float* w = W + (long)c * H3 + (long)pl * Rp;
-      float a = 0.f;
-      for (int rail = R4; rail < Rp; rail++) a += w[rail];
-      acc = r * a;
-    }
+  const int L = Rp - R4;
+  for (int sg = w; sg < 192; sg += 4) {
+    const int c = sg / 3, pl = sg - 3 * c;
+    const float* p = W + (long)c * H3 + (long)pl * Rp + R4;
+    float a = 0.f;
+    for (int i = lane; i < L; i += 64) a += p[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+    if (lane == 0) seg_sum[sg] = a;
   }
-  red[t] = acc;
   __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
-    if (t < st) red[t] += red[t + st];
-    __syncthreads();
+  if (t < 64) {
+    const float wp = (seg_sum[3 * t] + seg_sum[3 * t + 1]) + seg_sum[3 * t + 2];
+    if (wpad_out) wpad_out[(long)o * 64 + t] = wp;
+    red[t] = fmaxf(conv_b[t], 0.f) * wp;
   }
-  if (t == 0) bias2[o] = (o < 512 ? bias_a[o] : bias_v[o - 512]) + red[0];
+  __syncthreads();
+  if (t == 0) {
+    float acc = 0.f;
+    for (int c = 0; c < 64; c++) acc += red[c];
+    bias2[o] = (o < 512 ? bias_a[o] : bias_v[o - 512]) + acc;
+  }
 }
 
 // The split-K reduction of the first dense layer (both streams) with its bias and ReLU, then the output layers and
@@ -1293,6 +1312,44 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 4) void conv_u8_kernel(
   }
 }
 
+// ---- backward pass over the used rails: what the empty rails contribute ---------------------------------------------
+// The first dense layer's weights under the empty rails see the constant relu(conv_b[c]) for every sample, so their
+// gradient is dW[o][c*H3 + plane*Rp + rail] = relu(conv_b[c]) * gsum[o] (gsum = the layer's bias gradient, the column
+// sums of dhid) for rail >= R4.  One workgroup per output unit, lanes along a segment's consecutive weights.
+__global__ __launch_bounds__(256) void fc1_wgrad_padding_kernel(const float* __restrict__ gsum, const float* __restrict__ conv_b,
+                                                                float* __restrict__ dWa, float* __restrict__ dWv, long K1, int H3,
+                                                                int Rp, int R4) {
+  const int o = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float* W = o < 512 ? dWa + (long)o * K1 : dWv + (long)(o - 512) * K1;
+  const float go = gsum[o];
+  const int L = Rp - R4;
+  for (int sg = w; sg < 192; sg += 4) {
+    const int c = sg / 3, pl = sg - 3 * c;
+    const float v = fmaxf(conv_b[c], 0.f) * go;
+    float* p = W + (long)c * H3 + (long)pl * Rp + R4;
+    for (int i = lane; i < L; i += 64) p[i] = v;
+  }
+}
+
+// ... and the convolution's bias gradient gains, for every filter that is active on an empty row (conv_b[c] > 0), the
+// sum over those rows of the activation gradient: sum over o of gsum[o] * wpad[o][c] (wpad: fc1_padding_bias_kernel).
+// One workgroup: thread (c, part) sums every sixteenth o, the parts meet in LDS in a fixed order.
+__global__ __launch_bounds__(1024) void conv_bias_padding_kernel(const float* __restrict__ gsum, const float* __restrict__ wpad,
+                                                                 const float* __restrict__ conv_b, float* __restrict__ db) {
+  __shared__ float sm[16][64];
+  const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+  float a = 0.f;
+  for (int o = part; o < 1024; o += 16) a += gsum[o] * wpad[(long)o * 64 + c];
+  sm[part][c] = a;
+  __syncthreads();
+  if (part == 0 && conv_b[c] > 0.f) {
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) v += sm[i][c];
+    db[c] += v;
+  }
+}
+
 // ---- the convolution's weight and bias gradients straight from uint8 observations --------------------------------
 // dWc[c][k] = sum over samples b and rows h of dx1[b][c][h] * s[b][h][k],  dbias[c] = sum of dx1[b][c][h].
 // On the matrix cores with the rows (b,h) as the inner dimension, 16 rows per instruction: A = dx1, fp32 split into
@@ -1704,16 +1761,15 @@ static int dqn_rails_used(int B, int Rp, int rails_used) {
 // the R4 used rails of each plane only (x1c [B,64,3*R4]), the first dense layer multiplies those columns of its weights
 // (segments of R4 in rows of 3*Rp per filter) and the empty rails enter through the bias (fc1_padding_bias_kernel).
 // bias2: 1024 floats of workspace.
-static int dqn_forward_rails(const float* params, const uint8_t* obs_u8, int plane_stride, int B, int Rp, int R4, int T1,
-                             int NA, float* x1c, float* hid, float* part, float* bias2, float* q, hipStream_t stream) {
+// The dense layers behind a convolution over the used rails: x1c [B,64,3*R4] -> hid, q.  bias2: 1024 floats of
+// workspace; wpad_out: 1024*64 floats or nullptr (fc1_padding_bias_kernel).
+static int dqn_dense_stage_rails(const float* params, int B, int Rp, int R4, int T1, int NA, const float* x1c, float* hid,
+                                 float* part, float* bias2, float* wpad_out, float* q, hipStream_t stream) {
   const int H3 = 3 * Rp;
   DqnLayout L(H3, T1, NA);
-  // the byte convolution addresses a row as (sample, plane, rail) with plane_stride bytes between planes: with R4 rails
-  // per plane instead of Rp it reads the used rails and writes the compact activations
-  int rc = dqn_conv_stage(params, nullptr, obs_u8, plane_stride, B, 3 * R4, T1, NA, x1c, stream);
-  if (rc) return rc;
+  int rc;
   hipLaunchKernelGGL(flm::fc1_padding_bias_kernel, dim3(1024), dim3(256), 0, stream, params + L.a1_w, params + L.v1_w,
-                     params + L.a1_b, params + L.v1_b, params + L.conv_b, L.K1, H3, Rp, R4, bias2);
+                     params + L.a1_b, params + L.v1_b, params + L.conv_b, L.K1, H3, Rp, R4, bias2, wpad_out);
   const long Kc = 192L * R4;
   const int nks = fc1_k_slices(B);
   const int ks = (int)(((Kc + nks - 1) / nks + XBK - 1) / XBK * XBK);
@@ -1722,7 +1778,7 @@ static int dqn_forward_rails(const float* params, const uint8_t* obs_u8, int pla
   g.M = B; g.N = 512; g.K = (int)Kc; g.lda = Kc; g.ldb = L.K1; g.ldc = 1024;
   g.a_zs = 0; g.b_zs = L.v1_w - L.a1_w; g.c_zs = (long)B * 1024; g.c_gs = 512; g.groups = 2; g.ksplit = ks;
   g.b_seg_len = R4; g.b_seg_stride = Rp; g.b_seg_magic = (unsigned)((0x100000000ULL + (unsigned)R4 - 1) / (unsigned)R4);
-  if ((rc = flm::launch_gemm<true, true, flm::EPI_PLAIN, true>(g, 2 * nks, stream))) return rc;
+  if ((rc = flm::launch_gemm<true, true, flm::EPI_PLAIN, 1>(g, 2 * nks, stream))) return rc;
   if ((((uintptr_t)part | (uintptr_t)hid | (uintptr_t)bias2) & 15) == 0) {
     hipLaunchKernelGGL(flm::fc1_reduce_head_kernel, dim3(B), dim3(256), 0, stream, part, nks, B, bias2, bias2 + 512, hid,
                        params + L.a2_w, params + L.a2_b, params + L.v2_w, params + L.v2_b, NA, q);
@@ -1735,6 +1791,14 @@ static int dqn_forward_rails(const float* params, const uint8_t* obs_u8, int pla
   }
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
+}
+
+static int dqn_forward_rails(const float* params, const uint8_t* obs_u8, int plane_stride, int B, int Rp, int R4, int T1,
+                             int NA, float* x1c, float* hid, float* part, float* bias2, float* q, hipStream_t stream) {
+  // the byte convolution addresses a row as (sample, plane, rail) with plane_stride bytes between planes: with R4 rails
+  // per plane instead of Rp it reads the used rails and writes the compact activations
+  const int rc = dqn_conv_stage(params, nullptr, obs_u8, plane_stride, B, 3 * R4, T1, NA, x1c, stream);
+  return rc ? rc : dqn_dense_stage_rails(params, B, Rp, R4, T1, NA, x1c, hid, part, bias2, nullptr, q, stream);
 }
 
 extern "C" int flm_dqn_forward(const float* params, const float* x, int B, int H3, int T1, int NA, float* workspace,
@@ -1807,7 +1871,8 @@ extern "C" long flm_dqn_learn_workspace(int B, int H3, int T1, int NA) {
          + (long)B * 64 * H3                                  // dx1
          + learn_cpart_floats(B, T1)                          // conv weight-gradient partials
          + learn_part_floats(B)                               // split-K partials of the first dense layer
-         + (((5L * NA + 2) * B + 64 + 3) & ~3L);              // three q's, dq, dadv; dval, squared errors (whole 16 bytes)
+         + (((5L * NA + 2) * B + 64 + 3) & ~3L)               // three q's, dq, dadv; dval, squared errors (whole 16 bytes)
+         + 2 * 1024 + 1024 * 64 + 1024;                       // used-rails form: two bias vectors, wpad, column sums of dhid
 }
 
 // Forward passes, loss and backward of one learn step (src/agent.py:94-114); grads gets dLoss/dparams of
@@ -1821,6 +1886,7 @@ extern "C" long flm_dqn_learn_workspace(int B, int H3, int T1, int NA) {
 // gradients (the floats before the split).  A data-parallel caller sends the first part on its way between the two.
 struct LearnWorkspace {
   float *x1, *hid, *x1n, *hidn, *x1t, *hidt, *dhid, *dx1, *cpart, *part, *q, *qn, *qt, *dq, *dadv, *dval, *sq;
+  float *bias2, *wpad, *gsum;   // used-rails form
   LearnWorkspace(float* ws, int B, int H3, int T1, int NA) {
     // x1 / x1n, hid / hidn and q / qn are adjacent: the local network sees [s; s'] as one batch of 2B
     const long n_x1 = (long)B * 64 * H3, n_hid = (long)B * 1024;
@@ -1834,15 +1900,24 @@ struct LearnWorkspace {
     q = part + learn_part_floats(B);
     qn = q + (long)NA * B; qt = qn + (long)NA * B; dq = qt + (long)NA * B;
     dadv = dq + (long)NA * B; dval = dadv + (long)NA * B; sq = dval + B;
+    bias2 = q + (((5L * NA + 2) * B + 64 + 3) & ~3L);
+    wpad = bias2 + 2 * 1024;
+    gsum = wpad + 1024 * 64;
   }
 };
 
 static int learn_dense_half(const float* local, const float* target, const float* s, const float* s_next,
                             const uint8_t* s_u8, const uint8_t* sn_u8, int plane_stride, const int64_t* action,
                             const float* reward, const float* done, float gamma, int double_dqn, int B, int H3, int T1,
-                            int NA, const LearnWorkspace& w, float* grads, float* loss_out, hipStream_t stream) {
+                            int NA, const LearnWorkspace& w, float* grads, float* loss_out, hipStream_t stream, int R4 = 0) {
   DqnLayout L(H3, T1, NA);
   int rc;
+  // R4 > 0 (uint8 observations only): rails [R4, Rp) are empty in every plane of every observation; the convolutions and
+  // the products of the first dense layer run over the used rails (activations [.,64,3*R4]), the empty ones enter in
+  // closed form (fc1_padding_bias_kernel, fc1_wgrad_padding_kernel, conv_bias_padding_kernel)
+  const int Rp = H3 / 3;
+  const int H3c = R4 ? 3 * R4 : H3;                 // rows per sample the convolution computes
+  const long n_x1c = (long)B * 64 * H3c;
   if (s_u8 && !flm::conv_wgrad_u8_tiles(T1)) {      // (the byte form of the weight gradient needs no float copy)
     if ((long)B * 3 > 65535) return FLM_E_ARG;
     hipLaunchKernelGGL(flm::obs_to_f32_kernel, dim3(flm::obs_to_f32_pieces(H3 / 3, T1), B * 3), dim3(256), 0, stream, s_u8, B,
@@ -1859,22 +1934,30 @@ static int learn_dense_half(const float* local, const float* target, const float
   bool target_conv_done = false;
   if (adjacent && s_u8) {
     // ... and the target network's convolution over the next states rides in the same launch
-    if ((rc = dqn_conv_stage(local, nullptr, s_u8, plane_stride, 2 * B, H3, T1, NA, w.x1, stream, target, sn_u8, B, w.x1t)))
+    if ((rc = dqn_conv_stage(local, nullptr, s_u8, plane_stride, 2 * B, H3c, T1, NA, w.x1, stream, target, sn_u8, B, w.x1t)))
       return rc;
     target_conv_done = true;
   } else if (adjacent) {
     if ((rc = dqn_conv_stage(local, s, nullptr, plane_stride, 2 * B, H3, T1, NA, w.x1, stream))) return rc;
   } else {
-    if ((rc = dqn_conv_stage(local, s_u8 ? nullptr : s, s_u8, plane_stride, B, H3, T1, NA, w.x1, stream))) return rc;
-    if (double_dqn && (rc = dqn_conv_stage(local, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, NA, w.x1n, stream)))
+    if ((rc = dqn_conv_stage(local, s_u8 ? nullptr : s, s_u8, plane_stride, B, H3c, T1, NA, w.x1, stream))) return rc;
+    if (double_dqn && (rc = dqn_conv_stage(local, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3c, T1, NA, w.x1 + n_x1c,
+                                           stream)))
       return rc;
   }
-  if ((rc = dqn_dense_stage(local, double_dqn ? 2 * B : B, H3, T1, NA, w.x1, w.hid, w.part, w.q, stream))) return rc;
-  if (target_conv_done)
-    rc = dqn_dense_stage(target, B, H3, T1, NA, w.x1t, w.hidt, w.part, w.qt, stream);
-  else
-    rc = dqn_forward_impl(target, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, NA, w.x1t, w.hidt, w.part, w.qt,
-                          stream);
+  const int n_local = double_dqn ? 2 * B : B;
+  if (R4) {
+    if ((rc = dqn_dense_stage_rails(local, n_local, Rp, R4, T1, NA, w.x1, w.hid, w.part, w.bias2, w.wpad, w.q, stream))) return rc;
+    if (!target_conv_done && (rc = dqn_conv_stage(target, nullptr, sn_u8, plane_stride, B, H3c, T1, NA, w.x1t, stream))) return rc;
+    rc = dqn_dense_stage_rails(target, B, Rp, R4, T1, NA, w.x1t, w.hidt, w.part, w.bias2 + 1024, nullptr, w.qt, stream);
+  } else {
+    if ((rc = dqn_dense_stage(local, n_local, H3, T1, NA, w.x1, w.hid, w.part, w.q, stream))) return rc;
+    if (target_conv_done)
+      rc = dqn_dense_stage(target, B, H3, T1, NA, w.x1t, w.hidt, w.part, w.qt, stream);
+    else
+      rc = dqn_forward_impl(target, s_u8 ? nullptr : s_next, sn_u8, plane_stride, B, H3, T1, NA, w.x1t, w.hidt, w.part, w.qt,
+                            stream);
+  }
   if (rc) return rc;
   bool mean_done = false;
   if (double_dqn && B <= 1024) {
@@ -1897,21 +1980,34 @@ static int learn_dense_half(const float* local, const float* target, const float
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   // first dense layer: weight gradients dW[n,j] = sum_b dhid[b,n] * x1[b,j], both streams as two groups of one launch
   // (more workgroups per launch: fewer idle matrix pipes in the last round); bias gradients = column sums
+  hipLaunchKernelGGL(flm::colsum_kernel, dim3(16), dim3(1024), 0, stream, w.dhid, B, 1024, 1024L, grads + L.a1_b, 512,
+                     grads + L.v1_b);
   GemmArgs g{};
   g.A = w.dhid; g.B = w.x1; g.C = grads + L.a1_w;
   g.M = 512; g.N = (int)L.K1; g.K = B; g.lda = 1024; g.ldb = L.K1; g.ldc = L.K1;
   g.ksplit = B; g.groups = 2; g.a_zs = 512; g.b_zs = 0; g.c_zs = 0; g.c_gs = L.v1_w - L.a1_w; g.x_slowest = 1;
-  if ((rc = flm::launch_gemm<false, false, flm::EPI_PLAIN>(g, 2, stream))) return rc;
-  hipLaunchKernelGGL(flm::colsum_kernel, dim3(16), dim3(1024), 0, stream, w.dhid, B, 1024, 1024L, grads + L.a1_b, 512,
-                     grads + L.v1_b);
+  if (R4) {
+    // over the used rails: the columns of the product are scattered into the rows of dW, the rest of dW is filled from
+    // the column sums (a copy of them in the workspace: a data-parallel caller may be reducing grads by then)
+    const long Kc = 192L * R4;
+    g.N = (int)Kc; g.ldb = Kc;
+    g.b_seg_len = R4; g.b_seg_stride = Rp; g.b_seg_magic = (unsigned)((0x100000000ULL + (unsigned)R4 - 1) / (unsigned)R4);
+    if ((rc = flm::launch_gemm<false, false, flm::EPI_PLAIN, 3>(g, 2, stream))) return rc;
+    hipLaunchKernelGGL(flm::colsum_kernel, dim3(16), dim3(1024), 0, stream, w.dhid, B, 1024, 1024L, w.gsum, 512, w.gsum + 512);
+    hipLaunchKernelGGL(flm::fc1_wgrad_padding_kernel, dim3(1024), dim3(256), 0, stream, w.gsum, local + L.conv_b,
+                       grads + L.a1_w, grads + L.v1_w, L.K1, H3, Rp, R4);
+  } else {
+    if ((rc = flm::launch_gemm<false, false, flm::EPI_PLAIN>(g, 2, stream))) return rc;
+  }
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
 }
 
 static int learn_conv_half(const float* local, const float* s, const uint8_t* s_u8, int plane_stride, int B, int H3, int T1,
-                           int NA, const LearnWorkspace& w, float* grads, hipStream_t stream) {
+                           int NA, const LearnWorkspace& w, float* grads, hipStream_t stream, int R4 = 0) {
   DqnLayout L(H3, T1, NA);
   int rc;
+  const int Rp = H3 / 3;
   // gradient w.r.t. the conv activations: dx1 = [dhid_adv dhid_val] * [W_adv; W_val], zero where x1 == 0: one product
   // over K = 1024 (the two weight blocks are not adjacent: the value block starts v1_w - a1_w - 512*K1 floats late)
   {
@@ -1919,19 +2015,31 @@ static int learn_conv_half(const float* local, const float* s, const uint8_t* s_
     g.A = w.dhid; g.B = local + L.a1_w; g.C = w.dx1; g.mask = w.x1;
     g.M = B; g.N = (int)L.K1; g.K = 1024; g.lda = 1024; g.ldb = L.K1; g.ldc = L.K1;
     g.b_break_k = 512; g.b_break_off = (L.v1_w - L.a1_w) - 512L * L.K1; g.x_slowest = 1;
-    if ((rc = flm::launch_gemm<true, false, flm::EPI_MASK>(g, 1, stream))) return rc;
+    if (R4) {            // over the used rails: the columns of the product are those of the compact activations
+      const long Kc = 192L * R4;
+      g.N = (int)Kc; g.ldc = Kc;
+      g.b_seg_len = R4; g.b_seg_stride = Rp; g.b_seg_magic = (unsigned)((0x100000000ULL + (unsigned)R4 - 1) / (unsigned)R4);
+      if ((rc = flm::launch_gemm<true, false, flm::EPI_MASK, 2>(g, 1, stream))) return rc;
+    } else {
+      if ((rc = flm::launch_gemm<true, false, flm::EPI_MASK>(g, 1, stream))) return rc;
+    }
   }
   // conv weights and bias from the observation bytes where the horizon allows: one launch and its reduction
   const int nt = s_u8 ? flm::conv_wgrad_u8_tiles(T1) : 0;
   if (nt) {
     float* dW = grads + L.conv_w;
     float* db = grads + L.conv_b;
+    const int rails = R4 ? R4 : Rp;          // rails per plane in dx1 (the kernel steps through the planes by plane_stride)
     switch (nt) {
-      case 1: rc = flm::launch_conv_wgrad_u8<1>(w.dx1, s_u8, B, H3 / 3, T1, plane_stride, w.cpart, dW, db, stream); break;
-      case 2: rc = flm::launch_conv_wgrad_u8<2>(w.dx1, s_u8, B, H3 / 3, T1, plane_stride, w.cpart, dW, db, stream); break;
-      case 3: rc = flm::launch_conv_wgrad_u8<3>(w.dx1, s_u8, B, H3 / 3, T1, plane_stride, w.cpart, dW, db, stream); break;
-      case 4: rc = flm::launch_conv_wgrad_u8<4>(w.dx1, s_u8, B, H3 / 3, T1, plane_stride, w.cpart, dW, db, stream); break;
-      default: rc = flm::launch_conv_wgrad_u8<5>(w.dx1, s_u8, B, H3 / 3, T1, plane_stride, w.cpart, dW, db, stream); break;
+      case 1: rc = flm::launch_conv_wgrad_u8<1>(w.dx1, s_u8, B, rails, T1, plane_stride, w.cpart, dW, db, stream); break;
+      case 2: rc = flm::launch_conv_wgrad_u8<2>(w.dx1, s_u8, B, rails, T1, plane_stride, w.cpart, dW, db, stream); break;
+      case 3: rc = flm::launch_conv_wgrad_u8<3>(w.dx1, s_u8, B, rails, T1, plane_stride, w.cpart, dW, db, stream); break;
+      case 4: rc = flm::launch_conv_wgrad_u8<4>(w.dx1, s_u8, B, rails, T1, plane_stride, w.cpart, dW, db, stream); break;
+      default: rc = flm::launch_conv_wgrad_u8<5>(w.dx1, s_u8, B, rails, T1, plane_stride, w.cpart, dW, db, stream); break;
+    }
+    if (rc == FLM_OK && R4) {
+      hipLaunchKernelGGL(flm::conv_bias_padding_kernel, dim3(1), dim3(1024), 0, stream, w.gsum, w.wpad, local + L.conv_b, db);
+      if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
     }
     return rc;
   }
@@ -1957,13 +2065,13 @@ static int learn_conv_half(const float* local, const float* s, const uint8_t* s_
 static int learn_grads_impl(const float* local, const float* target, const float* s, const float* s_next,
                             const uint8_t* s_u8, const uint8_t* sn_u8, int plane_stride, const int64_t* action,
                             const float* reward, const float* done, float gamma, int double_dqn, int B, int H3, int T1,
-                            int NA, float* ws, float* grads, float* loss_out, hipStream_t stream, int phase = 0) {
+                            int NA, float* ws, float* grads, float* loss_out, hipStream_t stream, int phase = 0, int R4 = 0) {
   const LearnWorkspace w(ws, B, H3, T1, NA);
   int rc = FLM_OK;
   if (phase != 2)
     rc = learn_dense_half(local, target, s, s_next, s_u8, sn_u8, plane_stride, action, reward, done, gamma, double_dqn, B, H3,
-                          T1, NA, w, grads, loss_out, stream);
-  if (rc == FLM_OK && phase != 1) rc = learn_conv_half(local, s, s_u8, plane_stride, B, H3, T1, NA, w, grads, stream);
+                          T1, NA, w, grads, loss_out, stream, R4);
+  if (rc == FLM_OK && phase != 1) rc = learn_conv_half(local, s, s_u8, plane_stride, B, H3, T1, NA, w, grads, stream, R4);
   return rc;
 }
 
@@ -2018,6 +2126,22 @@ extern "C" int flm_dqn_learn_grads_u8_phase(const float* local, const float* tar
   float* s_f32 = ws + flm_dqn_learn_workspace(B, H3, T1, NA);
   return learn_grads_impl(local, target, s_f32, nullptr, s, s_next, plane_stride, action, reward, done, gamma, double_dqn, B,
                           H3, T1, NA, ws, grads, loss_out, (hipStream_t)stream, phase);
+}
+
+extern "C" int flm_dqn_learn_grads_u8_rails(const float* local, const float* target, const uint8_t* s, const uint8_t* s_next,
+                                            int plane_stride, const int64_t* action, const float* reward, const float* done,
+                                            float gamma, int double_dqn, int B, int Rp, int T1, int NA, int rails_used,
+                                            float* ws, float* grads, float* loss_out, int phase, void* stream) {
+  if (!local || !target || !s || !s_next || !action || !reward || !done || !ws || !grads || !loss_out) return FLM_E_ARG;
+  if (B <= 0 || Rp <= 0 || T1 <= 0 || (long)plane_stride < (long)Rp * T1 || !actions_ok(NA) || phase < 0 || phase > 2 ||
+      rails_used < 0 || rails_used > Rp)
+    return FLM_E_ARG;
+  const int H3 = 3 * Rp;
+  // the used-rails form needs the byte form of the convolution's weight gradient (no float copy of the states exists)
+  const int R4 = flm::conv_wgrad_u8_tiles(T1) ? dqn_rails_used(B, Rp, rails_used) : 0;
+  float* s_f32 = ws + flm_dqn_learn_workspace(B, H3, T1, NA);
+  return learn_grads_impl(local, target, s_f32, nullptr, s, s_next, plane_stride, action, reward, done, gamma, double_dqn, B,
+                          H3, T1, NA, ws, grads, loss_out, (hipStream_t)stream, phase, R4);
 }
 
 extern "C" int flm_dqn_adam(float* params, const float* grads, float* m, float* v, long n, double lr, double beta1,

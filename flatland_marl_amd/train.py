@@ -150,7 +150,9 @@ class BatchedTrainer:
 
     def _learn(self):
         b = self.ro.b
-        self.agent.learn_obs(self.replay.sample(self.agent.args.batch_size), self.agent.args.gamma, b.plane_stride)
+        # every observation in the memory comes from this batch of environments: rails beyond its largest count are empty
+        self.agent.learn_obs(self.replay.sample(self.agent.args.batch_size), self.agent.args.gamma, b.plane_stride,
+                             rails_used=self.ro.rails_used())
         self.n_learn += 1
 
     def step(self, train=True):

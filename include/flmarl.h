@@ -461,6 +461,20 @@ int flm_dqn_learn_grads_u8_phase(const float* local, const float* target, const 
                                  float gamma, int double_dqn, int B, int Rp, int T1, int NA, float* workspace,
                                  float* grads, float* loss_out, int phase, void* stream);
 
+/* flm_dqn_learn_grads_u8 (phase 0) or one half of it (phase 1 / 2, as flm_dqn_learn_grads_u8_phase) for observations
+ * whose rails [rails_used, Rp) are empty in every plane, states and next states alike (see flm_dqn_forward_u8_rails).
+ * Forward passes and the products of the backward pass run over the used rails only; what the empty rails contribute
+ * is added in closed form: to the first dense layer's pre-activations a vector per network, to its weight gradient
+ * relu(conv bias[c]) * (the layer's bias gradient) under every empty row, to the convolution's bias gradient the
+ * summed activation gradient of those rows; the convolution's weight gradient gets nothing from rows of zeros.  Same
+ * loss and gradients as flm_dqn_learn_grads_u8 up to fp32 rounding.  Falls back to the plain form when too few rails
+ * are empty, for B <= 8 and for horizons beyond the byte form of the convolution's weight gradient (T1 > 159).
+ * Workspace: flm_dqn_learn_workspace_u8. */
+int flm_dqn_learn_grads_u8_rails(const float* local, const float* target, const uint8_t* s, const uint8_t* s_next,
+                                 int plane_stride, const int64_t* action, const float* reward, const float* done,
+                                 float gamma, int double_dqn, int B, int Rp, int T1, int NA, int rails_used,
+                                 float* workspace, float* grads, float* loss_out, int phase, void* stream);
+
 /* Uniform sampling without replacement from a replay memory that lives in device memory, and the gather of the
  * sampled transitions.  Replaces ReplayBuffer.sample, src/agent.py:159-174 (random.sample over the deque, then
  * one stacked tensor per field).

@@ -713,3 +713,70 @@ def test_forward_over_the_used_rails_matches_the_plain_forward(Rp, T1, B, rails)
     if ((rails + 3) & ~3) + 4 <= Rp and B > 8:
         got2 = net.forward_obs(buf2, ps, rails_used=rails).cpu().numpy()
         assert np.array_equal(got2, got)
+
+
+@pytest.mark.parametrize("Rp,T1,B,rails,ddqn", [(70, 151, 64, 17, 1), (23, 61, 40, 5, 1), (100, 151, 33, 14, 1),
+                                                (30, 96, 300, 9, 1), (26, 37, 48, 12, 0), (70, 151, 20, 66, 1)])
+def test_learn_over_the_used_rails_matches_the_plain_learn_step(Rp, T1, B, rails, ddqn):
+    """flm_dqn_learn_grads_u8_rails (rails from `rails` on empty in every observation: computed over the used rails,
+    the empty ones added in closed form) against flm_dqn_learn_grads_u8 on the same batch: the loss, and every gradient
+    within 1e-5 of its tensor's largest (the first dense layer's weights separately under the used and under the empty
+    rows); in two phases the same bits as in one call; next states behind the states and apart."""
+    import types
+    from flatland_marl_amd.agent import DQNAgent
+    from flatland_marl_amd._lib import call, ptr, query
+    ps = (Rp * T1 + 255) // 256 * 256
+    H3 = 3 * Rp
+    args = types.SimpleNamespace(prediction_depth=T1 - 1, lr=5e-5, buffer_size=10, batch_size=B, update_every=10,
+                                 gamma=0.99, tau=1e-3)
+    torch.manual_seed(5)
+    agent = DQNAgent(args, action_space=2, bitmap_height=H3)
+    with torch.no_grad():
+        flat = agent.qnetwork_local.flat_params()
+        flat.mul_(torch.exp(torch.randn(flat.shape, generator=torch.Generator().manual_seed(2))).to(flat.device))
+    local, target = agent.qnetwork_local.flat_params(), agent.qnetwork_target.flat_params()
+    target.copy_(local * 0.93)
+    g = torch.Generator().manual_seed(B + rails)
+    obs = torch.zeros((2 * B, 3, Rp, T1), dtype=torch.uint8)
+    obs[:, 0, :rails] = torch.randint(-1, 2, (2 * B, rails, T1), generator=g).to(torch.int8).view(torch.uint8)
+    obs[:, 1:, :rails] = torch.randint(0, 9, (2 * B, 2, rails, T1), generator=g).to(torch.uint8)
+    both = torch.full((2 * B, 3, ps), 55, dtype=torch.uint8)
+    both[:, :, :Rp * T1] = obs.view(2 * B, 3, Rp * T1)
+    both = both.cuda()
+    act = torch.randint(0, 2, (B,), generator=g).cuda()
+    rew = torch.randn(B, generator=g).cuda()
+    done = (torch.rand(B, generator=g) < 0.2).float().cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    n = local.numel()
+    ws = torch.empty(query("flm_dqn_learn_workspace_u8", B, Rp, T1, 2), device="cuda")
+    head = lambda s, sn: (ptr(local), ptr(target), ptr(s), ptr(sn), ps, ptr(act), ptr(rew), ptr(done), 0.97, ddqn, B, Rp, T1, 2)
+    want, loss_w = torch.zeros(n, device="cuda"), torch.zeros(1, device="cuda")
+    call("flm_dqn_learn_grads_u8", *head(both[:B], both[B:]), ptr(ws), ptr(want), ptr(loss_w), st)
+    got, loss_g = torch.zeros(n, device="cuda"), torch.zeros(1, device="cuda")
+    call("flm_dqn_learn_grads_u8_rails", *head(both[:B], both[B:]), rails, ptr(ws), ptr(got), ptr(loss_g), 0, st)
+    torch.cuda.synchronize()
+    assert torch.allclose(loss_g, loss_w, rtol=1e-5)
+    shapes = [(64, T1), (64,), (512, 64, 3, Rp), (512,), (512, 64, 3, Rp), (512,), (2, 512), (2,), (1, 512), (1,)]
+    off = 0
+    R4 = (rails + 3) & ~3
+    for shp in shapes:
+        k = int(np.prod(shp))
+        a, b = got[off:off + k].view(shp), want[off:off + k].view(shp)
+        parts = [(a, b)] if len(shp) != 4 else [(a[..., :R4], b[..., :R4]), (a[..., R4:], b[..., R4:])]
+        for x, y in parts:
+            if y.numel():
+                top = y.abs().max().item()
+                assert (x - y).abs().max().item() <= 1e-5 * top + 1e-30, (off, shp, (x - y).abs().max().item(), top)
+        off += k
+    assert off == n and want.abs().max().item() > 0
+    # two phases: the same bits as the one call
+    two, loss_t = torch.full((n,), 7.0, device="cuda"), torch.zeros(1, device="cuda")
+    call("flm_dqn_learn_grads_u8_rails", *head(both[:B], both[B:]), rails, ptr(ws), ptr(two), ptr(loss_t), 1, st)
+    call("flm_dqn_learn_grads_u8_rails", *head(both[:B], both[B:]), rails, ptr(ws), ptr(two), ptr(loss_t), 2, st)
+    # next states apart from the states: the same bits again
+    s_apart, sn_apart = both[:B].clone(), both[B:].clone()
+    apart, loss_a = torch.zeros(n, device="cuda"), torch.zeros(1, device="cuda")
+    call("flm_dqn_learn_grads_u8_rails", *head(s_apart, sn_apart), rails, ptr(ws), ptr(apart), ptr(loss_a), 0, st)
+    torch.cuda.synchronize()
+    assert torch.equal(two, got) and torch.equal(loss_t, loss_g)
+    assert torch.equal(apart, got) and torch.equal(loss_a, loss_g)
