@@ -408,6 +408,22 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
 
 // out[m*ldo + n] = relu(bias[n] + sum over z of part[z][m][n])  (split-K reduction with the layer's epilogue)
 // The bias of column n is bias0[n] for n < n_half and bias1[n - n_half] above (two layers side by side).
+// out[i] = mask[i] > 0 ? sum over z of part[z*n + i] : 0, four elements per thread, slices added in order
+// (n a multiple of 4, 16-byte aligned buffers)
+__global__ __launch_bounds__(256) void reduce_mask_kernel(const float* __restrict__ part, int nz, long n,
+                                                          const float* __restrict__ mask, float* __restrict__ out) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 s = *reinterpret_cast<const float4*>(part + i);
+  for (int z = 1; z < nz; z++) {
+    const float4 v = *reinterpret_cast<const float4*>(part + (long)z * n + i);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const float4 m = *reinterpret_cast<const float4*>(mask + i);
+  s.x = m.x > 0.f ? s.x : 0.f; s.y = m.y > 0.f ? s.y : 0.f; s.z = m.z > 0.f ? s.z : 0.f; s.w = m.w > 0.f ? s.w : 0.f;
+  *reinterpret_cast<float4*>(out + i) = s;
+}
+
 __global__ void reduce_bias_relu_kernel(const float* __restrict__ part, int nz, int M, int N, const float* __restrict__ bias0,
                                         const float* __restrict__ bias1, int n_half, float* __restrict__ out, long ldo) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -663,30 +679,35 @@ __global__ __launch_bounds__(64) void head_forward_kernel(const float* __restric
 // gives relu(conv bias) there for every sample, and their share of the first dense layer is the same vector for every
 // sample: bias2[o] = bias[o] + sum over filters c of relu(conv_b[c]) * wpad[o][c], where wpad[o][c] is the sum of
 // W[o][c*H3 + plane*Rp + rail] over the planes and the rails >= R4.  One workgroup per output unit o (advantage stream
-// first); a wave takes every fourth (filter, plane) segment, its lanes the segment's consecutive weights; all sums
-// in a fixed order.  wpad_out (optional): wpad[1024][64], which the backward pass needs as well.
+// first); all sums in a fixed order.  wpad_out (optional): wpad as [64][1024] (filter-major), which the backward pass needs as well.
 __global__ __launch_bounds__(256) void fc1_padding_bias_kernel(const float* __restrict__ Wa, const float* __restrict__ Wv,
                                                                const float* __restrict__ bias_a, const float* __restrict__ bias_v,
                                                                const float* __restrict__ conv_b, long K1, int H3, int Rp, int R4,
                                                                float* __restrict__ bias2, float* __restrict__ wpad_out) {
-  __shared__ float seg_sum[192];
+  __shared__ float lane_sum[64][65];
   __shared__ float red[64];
   const int o = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
   const float* W = o < 512 ? Wa + (long)o * K1 : Wv + (long)(o - 512) * K1;
   const int L = Rp - R4;
-  for (int sg = w; sg < 192; sg += 4) {
-    const int c = sg / 3, pl = sg - 3 * c;
-    const float* p = W + (long)c * H3 + (long)pl * Rp + R4;
-    float a = 0.f;
-    for (int i = lane; i < L; i += 64) a += p[i];
+  // a wave takes every fourth filter, its lanes the consecutive weights of a segment: 48 independent loads per lane
+  // and pass (16 filters x 3 planes); the lanes' sums of a filter meet in LDS and are added in lane order
+  float a[16];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
-    if (lane == 0) seg_sum[sg] = a;
+  for (int j = 0; j < 16; j++) a[j] = 0.f;
+  for (int i = lane; i < L; i += 64) {
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const float* p = W + (long)(w + 4 * j) * H3 + R4 + i;
+      a[j] += (p[0] + p[Rp]) + p[2 * Rp];
+    }
   }
+#pragma unroll
+  for (int j = 0; j < 16; j++) lane_sum[w + 4 * j][lane] = a[j];
   __syncthreads();
   if (t < 64) {
-    const float wp = (seg_sum[3 * t] + seg_sum[3 * t + 1]) + seg_sum[3 * t + 2];
-    if (wpad_out) wpad_out[(long)o * 64 + t] = wp;
+    float wp = 0.f;
+    for (int l = 0; l < 64; l++) wp += lane_sum[t][l];
+    if (wpad_out) wpad_out[(long)t * 1024 + o] = wp;             // [filter][output unit]
     red[t] = fmaxf(conv_b[t], 0.f) * wp;
   }
   __syncthreads();
@@ -1332,22 +1353,20 @@ __global__ __launch_bounds__(256) void fc1_wgrad_padding_kernel(const float* __r
 }
 
 // ... and the convolution's bias gradient gains, for every filter that is active on an empty row (conv_b[c] > 0), the
-// sum over those rows of the activation gradient: sum over o of gsum[o] * wpad[o][c] (wpad: fc1_padding_bias_kernel).
-// One workgroup: thread (c, part) sums every sixteenth o, the parts meet in LDS in a fixed order.
-__global__ __launch_bounds__(1024) void conv_bias_padding_kernel(const float* __restrict__ gsum, const float* __restrict__ wpad,
-                                                                 const float* __restrict__ conv_b, float* __restrict__ db) {
-  __shared__ float sm[16][64];
-  const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
-  float a = 0.f;
-  for (int o = part; o < 1024; o += 16) a += gsum[o] * wpad[(long)o * 64 + c];
-  sm[part][c] = a;
+// sum over those rows of the activation gradient: sum over o of gsum[o] * wpad[c][o] (wpad: fc1_padding_bias_kernel).
+// One workgroup per filter: thread t sums o = t, t + 256, ..., the partial sums meet in LDS in a fixed order.
+__global__ __launch_bounds__(256) void conv_bias_padding_kernel(const float* __restrict__ gsum, const float* __restrict__ wpad,
+                                                                const float* __restrict__ conv_b, float* __restrict__ db) {
+  __shared__ float sm[256];
+  const int c = blockIdx.x, t = threadIdx.x;
+  const float* wp = wpad + (long)c * 1024;
+  sm[t] = (gsum[t] * wp[t] + gsum[t + 256] * wp[t + 256]) + (gsum[t + 512] * wp[t + 512] + gsum[t + 768] * wp[t + 768]);
   __syncthreads();
-  if (part == 0 && conv_b[c] > 0.f) {
-    float v = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; i++) v += sm[i][c];
-    db[c] += v;
+  for (int st = 128; st > 0; st >>= 1) {
+    if (t < st) sm[t] += sm[t + st];
+    __syncthreads();
   }
+  if (t == 0 && conv_b[c] > 0.f) db[c] += sm[0];
 }
 
 // ---- the convolution's weight and bias gradients straight from uint8 observations --------------------------------
@@ -2019,7 +2038,19 @@ static int learn_conv_half(const float* local, const float* s, const uint8_t* s_
       const long Kc = 192L * R4;
       g.N = (int)Kc; g.ldc = Kc;
       g.b_seg_len = R4; g.b_seg_stride = Rp; g.b_seg_magic = (unsigned)((0x100000000ULL + (unsigned)R4 - 1) / (unsigned)R4);
-      if ((rc = flm::launch_gemm<true, false, flm::EPI_MASK, 2>(g, 1, stream))) return rc;
+      // 4 x 30 tiles (B = 512, 20 rails) would leave half the CUs idle: K is cut into slices whose partial sums (in the
+      // forward pass's K-slice buffer) are added up, and masked, by a second launch
+      const long n_out = (long)B * Kc;
+      const long fit = learn_part_floats(B) / n_out;
+      const int nks = fit >= 4 ? 4 : (fit >= 2 ? 2 : 1);
+      if (nks >= 2 && (((uintptr_t)w.part | (uintptr_t)w.x1 | (uintptr_t)w.dx1) & 15) == 0) {
+        g.C = w.part; g.mask = nullptr; g.ksplit = 1024 / nks; g.c_zs = n_out;
+        if ((rc = flm::launch_gemm<true, false, flm::EPI_PLAIN, 2>(g, nks, stream))) return rc;
+        hipLaunchKernelGGL(flm::reduce_mask_kernel, dim3((unsigned)((n_out / 4 + 255) / 256)), dim3(256), 0, stream, w.part, nks,
+                           n_out, w.x1, w.dx1);
+      } else {
+        if ((rc = flm::launch_gemm<true, false, flm::EPI_MASK, 2>(g, 1, stream))) return rc;
+      }
     } else {
       if ((rc = flm::launch_gemm<true, false, flm::EPI_MASK>(g, 1, stream))) return rc;
     }
@@ -2038,7 +2069,7 @@ static int learn_conv_half(const float* local, const float* s, const uint8_t* s_
       default: rc = flm::launch_conv_wgrad_u8<5>(w.dx1, s_u8, B, rails, T1, plane_stride, w.cpart, dW, db, stream); break;
     }
     if (rc == FLM_OK && R4) {
-      hipLaunchKernelGGL(flm::conv_bias_padding_kernel, dim3(1), dim3(1024), 0, stream, w.gsum, w.wpad, local + L.conv_b, db);
+      hipLaunchKernelGGL(flm::conv_bias_padding_kernel, dim3(64), dim3(256), 0, stream, w.gsum, w.wpad, local + L.conv_b, db);
       if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
     }
     return rc;
