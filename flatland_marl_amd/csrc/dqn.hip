@@ -2159,6 +2159,13 @@ extern "C" int flm_dqn_learn_grads_u8_phase(const float* local, const float* tar
                           H3, T1, NA, ws, grads, loss_out, (hipStream_t)stream, phase);
 }
 
+// rails per plane that flm_dqn_learn_grads_u8_rails computes over for these sizes (a multiple of four), 0 = it runs the
+// plain form: what a caller may leave out of the observations it hands over
+extern "C" long flm_dqn_learn_rails(int B, int Rp, int T1, int rails_used) {
+  if (B <= 0 || Rp <= 0 || T1 <= 0 || rails_used < 0 || rails_used > Rp) return 0;
+  return flm::conv_wgrad_u8_tiles(T1) ? dqn_rails_used(B, Rp, rails_used) : 0;
+}
+
 extern "C" int flm_dqn_learn_grads_u8_rails(const float* local, const float* target, const uint8_t* s, const uint8_t* s_next,
                                             int plane_stride, const int64_t* action, const float* reward, const float* done,
                                             float gamma, int double_dqn, int B, int Rp, int T1, int NA, int rails_used,
@@ -2169,7 +2176,7 @@ extern "C" int flm_dqn_learn_grads_u8_rails(const float* local, const float* tar
     return FLM_E_ARG;
   const int H3 = 3 * Rp;
   // the used-rails form needs the byte form of the convolution's weight gradient (no float copy of the states exists)
-  const int R4 = flm::conv_wgrad_u8_tiles(T1) ? dqn_rails_used(B, Rp, rails_used) : 0;
+  const int R4 = (int)flm_dqn_learn_rails(B, Rp, T1, rails_used);
   float* s_f32 = ws + flm_dqn_learn_workspace(B, H3, T1, NA);
   return learn_grads_impl(local, target, s_f32, nullptr, s, s_next, plane_stride, action, reward, done, gamma, double_dqn, B,
                           H3, T1, NA, ws, grads, loss_out, (hipStream_t)stream, phase, R4);

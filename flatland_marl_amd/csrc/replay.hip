@@ -71,6 +71,33 @@ __global__ __launch_bounds__(256) void replay_gather_kernel(const uint8_t* __res
   }
 }
 
+// The same gather for rows of n_planes planes of which only the first used_bytes matter (observations whose rails
+// beyond the environments' own are empty): those bytes of every plane are copied, the rest of the output rows is left
+// as it is.  One workgroup per (sampled transition, 16 KiB piece of the bytes to copy).
+__global__ __launch_bounds__(256) void replay_gather_planes_kernel(const uint8_t* __restrict__ state, const uint8_t* __restrict__ next_state,
+                                                                   const int64_t* __restrict__ action, const float* __restrict__ reward,
+                                                                   const float* __restrict__ done, const int32_t* __restrict__ idx,
+                                                                   long row_bytes, int n_planes, long plane_bytes, long used_bytes,
+                                                                   uint8_t* __restrict__ out_state, uint8_t* __restrict__ out_next,
+                                                                   int64_t* __restrict__ out_action, float* __restrict__ out_reward,
+                                                                   float* __restrict__ out_done) {
+  const int b = blockIdx.y;
+  const long src = (long)idx[b] * row_bytes, dst = (long)b * row_bytes;
+  const long total = used_bytes * n_planes;
+  const long lo = (long)blockIdx.x * 16384;
+  const long hi = lo + 16384 < total ? lo + 16384 : total;
+  for (long o = lo + (long)threadIdx.x * 16; o < hi; o += 256 * 16) {
+    const long pl = o / used_bytes, at = pl * plane_bytes + (o - pl * used_bytes);
+    *reinterpret_cast<uint4*>(out_state + dst + at) = *reinterpret_cast<const uint4*>(state + src + at);
+    *reinterpret_cast<uint4*>(out_next + dst + at) = *reinterpret_cast<const uint4*>(next_state + src + at);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    out_action[b] = action[idx[b]];
+    out_reward[b] = reward[idx[b]];
+    out_done[b] = done[idx[b]];
+  }
+}
+
 // ---- storing a rollout step's transitions (default replay feeding of the training script, src/main.py:275-278) ----
 // Request i of the step (the departing agents, then the agents in front of a switch) is stored when it had a row to
 // act on (sel_row[i] >= 0); the stored requests take consecutive ring slots from `head` on in request order; if there
@@ -413,6 +440,26 @@ extern "C" int flm_replay_gather(const void* state, const void* next_state, cons
   hipLaunchKernelGGL(flm::replay_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)state,
                      (const uint8_t*)next_state, action, reward, done, idx, row_bytes, (uint8_t*)out_state, (uint8_t*)out_next,
                      out_action, out_reward, out_done);
+  FLM_CHECK_LAUNCH();
+  return FLM_OK;
+}
+
+extern "C" int flm_replay_gather_planes(const void* state, const void* next_state, const int64_t* action, const float* reward,
+                                        const float* done, const int32_t* idx, int batch, long row_bytes, int n_planes,
+                                        long plane_bytes, long used_bytes, void* out_state, void* out_next,
+                                        int64_t* out_action, float* out_reward, float* out_done, void* stream) {
+  if (!state || !next_state || !action || !reward || !done || !idx || !out_state || !out_next || !out_action || !out_reward ||
+      !out_done)
+    return FLM_E_ARG;
+  if (batch <= 0 || batch > 65535 || row_bytes <= 0 || (row_bytes & 15) || n_planes <= 0 || plane_bytes <= 0 ||
+      (plane_bytes & 15) || used_bytes <= 0 || (used_bytes & 15) || used_bytes > plane_bytes ||
+      (long)n_planes * plane_bytes > row_bytes)
+    return FLM_E_ARG;
+  if (((uintptr_t)state | (uintptr_t)next_state | (uintptr_t)out_state | (uintptr_t)out_next) & 15) return FLM_E_ARG;
+  dim3 grid((unsigned)((used_bytes * n_planes + 16383) / 16384), (unsigned)batch);
+  hipLaunchKernelGGL(flm::replay_gather_planes_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)state,
+                     (const uint8_t*)next_state, action, reward, done, idx, row_bytes, n_planes, plane_bytes, used_bytes,
+                     (uint8_t*)out_state, (uint8_t*)out_next, out_action, out_reward, out_done);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }

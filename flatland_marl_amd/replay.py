@@ -132,9 +132,10 @@ class DeviceReplay:
         self.draws += 1
         return idx
 
-    def sample(self, batch_size):
+    def sample(self, batch_size, used_bytes=0):
         """-> (states, actions, rewards, next_states, dones) of batch_size transitions.  The tensors are buffers of
-        this object: the next call overwrites them."""
+        this object: the next call overwrites them.  used_bytes > 0 (rows of planes, row_shape = (planes, plane bytes)):
+        only the first used_bytes of every plane are gathered, what lies behind them in the returned rows is stale."""
         B = int(batch_size)
         if self._out is None or self._out[0].shape[0] != B:
             dev = self.device
@@ -151,6 +152,13 @@ class DeviceReplay:
         st = torch.cuda.current_stream(self.device).cuda_stream
         call("flm_replay_sample", self.size, B, self.seed, self.draws & 0xFFFFFFFF, ptr(idx), st)
         self.draws += 1
-        call("flm_replay_gather", ptr(self.state), ptr(self.next_state), ptr(self.action), ptr(self.reward), ptr(self.done),
-             ptr(idx), B, self.row_bytes, ptr(s), ptr(sn), ptr(a), ptr(r), ptr(d), st)
+        used = (int(used_bytes) + 15) // 16 * 16
+        if used and len(self.row_shape) == 2 and self.dtype == torch.uint8 and used < self.row_shape[1] and \
+                self.row_shape[1] % 16 == 0:
+            call("flm_replay_gather_planes", ptr(self.state), ptr(self.next_state), ptr(self.action), ptr(self.reward),
+                 ptr(self.done), ptr(idx), B, self.row_bytes, self.row_shape[0], self.row_shape[1], used, ptr(s), ptr(sn),
+                 ptr(a), ptr(r), ptr(d), st)
+        else:
+            call("flm_replay_gather", ptr(self.state), ptr(self.next_state), ptr(self.action), ptr(self.reward),
+                 ptr(self.done), ptr(idx), B, self.row_bytes, ptr(s), ptr(sn), ptr(a), ptr(r), ptr(d), st)
         return s, a, r, sn, d

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import parallel
-from ._lib import call, ptr
+from ._lib import call, ptr, query
 from .replay import DeviceReplay
 from .rollout import RolloutBatch
 
@@ -150,9 +150,12 @@ class BatchedTrainer:
 
     def _learn(self):
         b = self.ro.b
-        # every observation in the memory comes from this batch of environments: rails beyond its largest count are empty
-        self.agent.learn_obs(self.replay.sample(self.agent.args.batch_size), self.agent.args.gamma, b.plane_stride,
-                             rails_used=self.ro.rails_used())
+        # every observation in the memory comes from this batch of environments: rails beyond its largest count are
+        # empty, neither gathered nor computed
+        rails = self.ro.rails_used()
+        used = query("flm_dqn_learn_rails", self.agent.args.batch_size, b.Rp, b.T1, rails) * b.T1
+        self.agent.learn_obs(self.replay.sample(self.agent.args.batch_size, used_bytes=used), self.agent.args.gamma,
+                             b.plane_stride, rails_used=rails)
         self.n_learn += 1
 
     def step(self, train=True):

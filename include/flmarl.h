@@ -470,6 +470,7 @@ int flm_dqn_learn_grads_u8_phase(const float* local, const float* target, const 
  * loss and gradients as flm_dqn_learn_grads_u8 up to fp32 rounding.  Falls back to the plain form when too few rails
  * are empty, for B <= 8 and for horizons beyond the byte form of the convolution's weight gradient (T1 > 159).
  * Workspace: flm_dqn_learn_workspace_u8. */
+long flm_dqn_learn_rails(int B, int Rp, int T1, int rails_used);   /* rails per plane it computes over (0: the plain form runs) */
 int flm_dqn_learn_grads_u8_rails(const float* local, const float* target, const uint8_t* s, const uint8_t* s_next,
                                  int plane_stride, const int64_t* action, const float* reward, const float* done,
                                  float gamma, int double_dqn, int B, int Rp, int T1, int NA, int rails_used,
@@ -487,6 +488,13 @@ int flm_replay_sample(int size, int batch, uint32_t seed, uint32_t draw, int32_t
 int flm_replay_gather(const void* state, const void* next_state, const int64_t* action, const float* reward,
                       const float* done, const int32_t* idx, int batch, long row_bytes, void* out_state, void* out_next,
                       int64_t* out_action, float* out_reward, float* out_done, void* stream);
+/* flm_replay_gather for rows of n_planes planes, plane_bytes apart, of which only the first used_bytes matter
+ * (observations whose rails beyond the environments' own are empty, see flm_dqn_learn_grads_u8_rails): those bytes of
+ * every plane are gathered, the rest of the output rows is left as it is.  plane_bytes and used_bytes multiples of 16. */
+int flm_replay_gather_planes(const void* state, const void* next_state, const int64_t* action, const float* reward,
+                             const float* done, const int32_t* idx, int batch, long row_bytes, int n_planes,
+                             long plane_bytes, long used_bytes, void* out_state, void* out_next, int64_t* out_action,
+                             float* out_reward, float* out_done, void* stream);
 
 /* Storing one rollout step's transitions in the replay memory's ring.  Replaces the per-agent dqn.step(...) calls of
  * the training script's default feeding mode, src/main.py:275-278 (-> ReplayBuffer.add, src/agent.py:153-157), for

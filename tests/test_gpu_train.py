@@ -444,6 +444,14 @@ def test_replay_sampling_kernel():
     s, ac, rw, sn, dn = rp.sample(B)
     assert torch.equal(s.cpu(), state[idx]) and torch.equal(sn.cpu(), nxt[idx]) and torch.equal(ac.cpu(), act[idx])
     assert torch.equal(rw.cpu(), rew[idx]) and torch.equal(dn.cpu(), done[idx])
+    # plane-wise gather: the first bytes of every plane arrive, what lies behind them in the buffers is left alone
+    for t in rp._out[:1] + rp._out[3:4]:
+        t.fill_(9)
+    rp.draws = 7
+    s2, ac2, rw2, sn2, dn2 = rp.sample(B, used_bytes=20)         # rounded up to 32 of the 48 bytes of a plane
+    assert torch.equal(s2[:, :, :32].cpu(), state[idx][:, :, :32]) and torch.equal(sn2[:, :, :32].cpu(), nxt[idx][:, :, :32])
+    assert bool((s2[:, :, 32:] == 9).all()) and bool((sn2[:, :, 32:] == 9).all())
+    assert torch.equal(ac2.cpu(), act[idx]) and torch.equal(rw2.cpu(), rew[idx]) and torch.equal(dn2.cpu(), done[idx])
     # the whole memory can be asked for; more than it holds cannot
     assert sorted(rp.sample_indices(n).cpu().tolist()) == list(range(n))
     with pytest.raises(ValueError):
