@@ -140,6 +140,13 @@ def rollout_sample(device, steps=40, workload="cfg2g", max_rails=70, rank=0, wor
     ref_steps = max(2, min(steps, ref_cadence_steps))
     out = {"unit": "env-steps/s", "config": {"workload": workload + ": " + desc, "envs_per_gpu": E, "n_gpus": world,
                                              "agents": A, "rails_padded": int(b.Rp),
+                                             "rails_used": int(ro.rails_used()),
+                                             "rails_note": "the environments of this workload have at most rails_used rails; "
+                                                           "the rows up to rails_padded are the reference's padding to max_rails "
+                                                           "(src/preprocessing.py:36-50): the network's kernels compute over the "
+                                                           "used rails and add the padding's share in closed form "
+                                                           "(flm_dqn_forward_u8_rails, flm_dqn_learn_grads_u8_rails), same "
+                                                           "results up to fp32 rounding",
                                              "depth": depth, "steps_timed": steps, "eps": 0.1,
                                              "speeds": "1, 1/2, 1/3, 1/4", "malfunction": malf}}
     for key, train, cap, steps in (("act_only", False, 4, steps), ("act_and_learn", True, 4, steps),
@@ -234,10 +241,15 @@ def dqn_sample(device, B=512, max_rails=100, depth=150):
     t_f = timed(lambda: agent.qnetwork_local.forward_obs(obs, ps))
     t_l = timed(lambda: agent.learn_obs((obs, act, r, obs_n, d), 0.99, ps))
     t_a = timed(lambda: agent.qnetwork_local(one), reps=30)
+    # the same batch when the environments have 20 rails and the other 80 are padding (rows of zeros)
+    both[:, :, 20 * T1:] = 0
+    t_fr = timed(lambda: agent.qnetwork_local.forward_obs(obs, ps, rails_used=20))
+    t_lr = timed(lambda: agent.learn_obs((obs, act, r, obs_n, d), 0.99, ps, rails_used=20))
     return {"workload": "batch %d, max_rails %d, depth %d, uint8 observations" % (B, max_rails, depth),
             "forward_ms": t_f, "forward_TFLOPs": fwd_flop / t_f / 1e9,
             "learn_step_ms": t_l, "learn_step_TFLOPs": 5 * fwd_flop / t_l / 1e9,
             "act_batch1_ms": t_a,
+            "forward_20_of_%d_rails_ms" % max_rails: t_fr, "learn_step_20_of_%d_rails_ms" % max_rails: t_lr,
             "note": "fp32 values; the matrix products run on the bf16 matrix cores with every fp32 operand split into "
                     "three bf16 terms (six partial products: one sixth of the bf16 peak = 417 TFLOP/s bounds them; "
                     "fp32 matrix instructions peak at 157); a learn step is three forward passes, the backward pass "
