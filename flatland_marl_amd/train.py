@@ -152,7 +152,7 @@ class BatchedTrainer:
         b = self.ro.b
         # every observation in the memory comes from this batch of environments: rails beyond its largest count are
         # empty, neither gathered nor computed
-        rails = self.ro.rails_used()
+        rails = self._rails_seen = max(getattr(self, "_rails_seen", 0), self.ro.rails_used())   # of anything ever stored
         used = query("flm_dqn_learn_rails", self.agent.args.batch_size, b.Rp, b.T1, rails) * b.T1
         self.agent.learn_obs(self.replay.sample(self.agent.args.batch_size, used_bytes=used), self.agent.args.gamma,
                              b.plane_stride, rails_used=rails)
