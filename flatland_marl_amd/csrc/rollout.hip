@@ -11,11 +11,14 @@ namespace flm {
 // leaf; then every lane completes one leaf by a greedy descent of at most max_depth moves, so the walks of
 // a request run side by side; last, leaves whose descent found no way are squeezed out in order.
 // More than cap_alt leaves is FLM_AGENT_OVERFLOW.
-// STAGE: one request per wave (G = 64) and the tables a descent reads copied into LDS first: the environment's
-// successor table (2 bytes per state) and choice table (8 bytes per state) and the distance row of the request's
-// target (2 bytes per state).  The kernel is bound by the latency of its longest descent, a chain of dependent
-// look-ups: forced steps take one look-up each, steps with a choice two (the choice entry, then the candidates'
-// distances), and from LDS both kinds run at LDS latency instead of a round trip to memory.
+// STAGE: one request per wave (G = 64).  The wave first works out, for every state of the environment, the move a
+// greedy walk towards this request's target takes there (the forced successor, or among the moves of least distance
+// the first of left, forward, right: what greedy_path() decides step by step) and keeps it in LDS as one word per
+// state - successor, action, "no way" - and, beside it, the move after that one.  A descent is then a chain of
+// look-ups of the same kind whatever the states are, two path elements per look-up, and the lanes of a request's
+// alternatives run in step.  The descent of greedy_path() carries the distance of the state it stands on and admits
+// only moves that lower it; in a distance map every state's best move does, so the table holds the same choice (the
+// first element, taken before any distance is known, is handled apart).
 #define FLM_ALT_STACK 32
 #define FLM_ALT_FRAME_INTS (2 * (FLM_ALT_STACK + 2) + 4 * FLM_ALT_STACK + 6 * FLM_ALT_STACK)   // per request
 
@@ -43,14 +46,20 @@ __global__ __launch_bounds__(64) void altpaths_kernel(
   const uint16_t* dist = dist_all + ((size_t)e * A + tslot[ga]) * capCells * 4;
   const uint16_t* succ = succ_all ? succ_all + (size_t)e * capCells * 4 : nullptr;
   const uint16_t* choice = succ_all && choice_all ? choice_all + (size_t)e * capCells * 16 : nullptr;
-  // STAGE: [capCells * 16] choice, [capCells * 4] successors, [capCells * 4] distances (16 bits each), [capCells] grid
-  // cell of every rail cell, [cap_alt][Lcap] the descents' records (capCells is even: every table is a whole number of
-  // 16-byte pieces)
-  uint16_t* choice_lds = reinterpret_cast<uint16_t*>(alt_frames + FLM_ALT_FRAME_INTS);
+  // STAGE: [capCells * 4] next move, [capCells * 4] the move after it (32 bits each), [capCells] grid cell of every rail
+  // cell, then the descents' records [cap_alt][Lcap]; before the descents that last region holds copies of the
+  // environment's choice table (8 bytes per state), successor table and the target's distance row (2 bytes per state
+  // each), from which the move tables are worked out (capCells is even: every table is whole 16-byte pieces)
+  uint32_t* next_lds = reinterpret_cast<uint32_t*>(alt_frames + FLM_ALT_FRAME_INTS);
+  uint32_t* next2_lds = next_lds + (size_t)capCells * 4;
+  int32_t* icell_lds = reinterpret_cast<int32_t*>(next2_lds + (size_t)capCells * 4);
+  uint32_t* rec_lds = reinterpret_cast<uint32_t*>(icell_lds + ((capCells + 3) & ~3));   // (on a 16-byte boundary)
+  uint16_t* choice_lds = reinterpret_cast<uint16_t*>(rec_lds);
   uint16_t* succ_lds = choice_lds + (size_t)capCells * 16;
   uint16_t* dist_lds = succ_lds + (size_t)capCells * 4;
-  int32_t* icell_lds = reinterpret_cast<int32_t*>(dist_lds + (size_t)capCells * 4);
-  uint32_t* rec_lds = reinterpret_cast<uint32_t*>(icell_lds + capCells);
+  constexpr uint32_t NO_MOVE = 0xFFFFFFFFu;
+  const int tcell_s = target_cell[ga];
+  const int tci_s = (STAGE && tcell_s >= 0 && tcell_s < HW) ? cell_idx[tcell_s] : -1;
   if (STAGE) {
     // (G = 64: the whole wave serves one request, e and the target are the same for every lane)
     const uint4* src_c = reinterpret_cast<const uint4*>(choice);
@@ -66,6 +75,37 @@ __global__ __launch_bounds__(64) void altpaths_kernel(
       dst_d[i] = src_d[i];
     }
     for (int i = lane; i < capCells; i += 64) icell_lds[i] = src_i[i];
+    __syncthreads();
+    const int capS = capCells * 4;
+    for (int st = lane; st < capS; st += 64) {
+      const unsigned nx = succ_lds[st];
+      uint32_t w = NO_MOVE;
+      if (nx != 0xFFFFu) {
+        w = nx | (2u << 16);                                   // forced: recorded as "forward"
+      } else {
+        const uint2 raw = *reinterpret_cast<const uint2*>(choice_lds + (size_t)st * 4);
+        const unsigned ns[3] = {raw.x & 0xFFFFu, raw.x >> 16, raw.y & 0xFFFFu};
+        unsigned best_d = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          const unsigned dd = ns[i] != 0xFFFFu ? (unsigned)dist_lds[ns[i]] : (unsigned)FLM_DIST_INF;
+          if (dd != FLM_DIST_INF && dd < best_d) {
+            best_d = dd;
+            w = ns[i] | (((raw.y >> 16) & 1u ? 2u : (unsigned)(1 + i)) << 16);
+          }
+        }
+      }
+      next_lds[st] = w;
+    }
+    __syncthreads();
+    // the move after the next one; none where the next state is on the target cell (a walk ends there)
+    for (int st = lane; st < capS; st += 64) {
+      const uint32_t w = next_lds[st];
+      uint32_t w2 = NO_MOVE;
+      if (w != NO_MOVE && (int)((w & 0xFFFFu) >> 2) != tci_s) w2 = next_lds[w & 0xFFFFu];
+      next2_lds[st] = w2;
+    }
+    __syncthreads();                  // the staged copies are done with: the records take their place
   }
   const int tcell = target_cell[ga];
   int32_t* out_len = alt_len + (size_t)g * cap_alt;
@@ -161,60 +201,36 @@ __global__ __launch_bounds__(64) void altpaths_kernel(
       } else if (start >= 0) {
         int n;
         if (STAGE) {
-          // The descent of greedy_path() on the staged tables, one dependent LDS look-up per forced step: an
-          // element is recorded as state | action << 16 | next heading << 20; cells and the output layout follow
-          // when all lanes copy the records out.
+          // The descent of greedy_path() on the request's move tables: an element is recorded as
+          // state | action << 16 | next heading << 20; cells and the output layout follow when all lanes copy the
+          // records out.
           uint32_t* rec = rec_lds + (size_t)j * Lcap;
           const int cap = Lcap - base;
-          const int tci = (tcell >= 0 && tcell < HW) ? cell_idx[tcell] : -1;
+          const int tci = tci_s;
           const int idx0 = cell_idx[start];
           n = -1;
           if (idx0 >= 0) {
             int st = idx0 * 4 + s_h[lane], depth = 0;
-            unsigned best_d = 0xFFFFFFFFu;
-            bool reach = false, dead = false;
+            bool dead = false;
             n = 0;
-            while ((st >> 2) != tci && depth < max_depth) {
-              unsigned nx = succ_lds[st];
-              if (nx != 0xFFFFu) {
-                if (!reach) {
-                  const unsigned d0 = dist_lds[st];
-                  if (d0 == FLM_DIST_INF) { dead = true; break; }
-                  best_d = d0;
-                  reach = true;
-                }
-                do {                       // a forced run never crosses a target cell: only the horizon ends it early
-                  if (n < cap) rec[n] = (unsigned)st | (2u << 16) | ((nx & 3u) << 20);
-                  n++;
-                  depth++;
-                  st = (int)nx;
-                  best_d -= 1;
-                  if (depth >= max_depth) break;
-                  nx = succ_lds[st];
-                } while (nx != 0xFFFFu);
-                continue;
-              }
-              const uint2 raw = *reinterpret_cast<const uint2*>(choice_lds + (size_t)st * 4);
-              const unsigned ns[3] = {raw.x & 0xFFFFu, raw.x >> 16, raw.y & 0xFFFFu};
-              int best = -1;
-              unsigned best_s = 0;
-#pragma unroll
-              for (int i = 0; i < 3; i++) {
-                if (ns[i] == 0xFFFFu) continue;
-                const unsigned dd = dist_lds[ns[i]];
-                if (dd != FLM_DIST_INF && dd < best_d) {
-                  best = i;
-                  best_d = dd;
-                  best_s = ns[i];
-                }
-              }
-              if (best < 0) { dead = true; break; }
-              const unsigned action = (raw.y >> 16) & 1u ? 2u : (unsigned)(1 + best);
-              if (n < cap) rec[n] = (unsigned)st | (action << 16) | ((best_s & 3u) << 20);
+            // a walk that starts on a forced move from a state that reaches nothing ends at once (greedy_path() learns
+            // the distance at its first forced step); everywhere else "no way" is the table's own mark
+            if ((st >> 2) != tci && max_depth > 0 && succ[st] != 0xFFFFu && dist[st] == FLM_DIST_INF) dead = true;
+            while (!dead && (st >> 2) != tci && depth < max_depth) {
+              const uint32_t w1 = next_lds[st], w2 = next2_lds[st];
+              if (w1 == NO_MOVE) { dead = true; break; }
+              const unsigned s1 = w1 & 0xFFFFu;
+              if (n < cap) rec[n] = (unsigned)st | (w1 & 0x70000u) | ((s1 & 3u) << 20);
               n++;
               depth++;
-              st = (int)best_s;
-              reach = true;
+              st = (int)s1;
+              if (w2 != NO_MOVE && depth < max_depth) {          // (s1 is not on the target cell: the table says so)
+                const unsigned s2 = w2 & 0xFFFFu;
+                if (n < cap) rec[n] = s1 | (w2 & 0x70000u) | ((s2 & 3u) << 20);
+                n++;
+                depth++;
+                st = (int)s2;
+              }
             }
             if (dead) {
               n = -1;
@@ -476,9 +492,10 @@ extern "C" int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const
     return FLM_E_ARG;
   int G = 1;                              // lanes per request
   while (G < cap_alt) G *= 2;
-  // one request per wave with the successor, choice, distance and cell tables and the descents' records in LDS when
-  // the tables exist, are 16-byte aligned per environment and target (an even capCells) and fit beside the frames
-  const size_t staged_lds = (size_t)FLM_ALT_FRAME_INTS * sizeof(int) + (size_t)capCells * 52 + (size_t)cap_alt * Lcap * 4 + 16;
+  // one request per wave with its move tables, the cell table and the descents' records in LDS when the successor and
+  // choice tables exist, are 8-byte aligned per environment (an even capCells) and everything fits beside the frames
+  const size_t staged_lds = (size_t)FLM_ALT_FRAME_INTS * sizeof(int) + (size_t)capCells * 32 + (size_t)((capCells + 3) & ~3) * 4 +
+                            std::max((size_t)capCells * 48, (size_t)cap_alt * Lcap * 4) + 16;
   const bool stage = succ && choice && idx_cell && (capCells & 1) == 0 && capCells * 4 <= 65535 &&
                      (((uintptr_t)succ | (uintptr_t)choice | (uintptr_t)dist) & 15) == 0 && staged_lds <= 64 * 1024;
   if (stage) {
