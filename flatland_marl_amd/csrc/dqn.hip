@@ -437,8 +437,9 @@ __global__ void reduce_bias_relu_kernel(const float* __restrict__ part, int nz, 
 
 // column sums: out[n] = sum_m X[m*ld + n], one workgroup per 64 columns, fixed summation order
 // (columns from n_split on go to out1: two destinations that are not adjacent, one launch)
+// copy (optional): all N sums once more, contiguous
 __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ X, int M, int N, long ld, float* __restrict__ out,
-                                                      int n_split, float* __restrict__ out1) {
+                                                      int n_split, float* __restrict__ out1, float* __restrict__ copy) {
   __shared__ float s[16][64];
   const int lane = threadIdx.x & 63, n = blockIdx.x * 64 + lane, w = threadIdx.x >> 6;
   // 16 waves split the rows; four independent partial sums per lane keep four loads in flight; every
@@ -462,6 +463,7 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
     for (int i = 0; i < 16; i++) acc += s[i][lane];
     if (n < n_split) out[n] = acc;
     else out1[n - n_split] = acc;
+    if (copy) copy[n] = acc;
   }
 }
 
@@ -1609,18 +1611,36 @@ static int launch_conv_u8(const uint8_t* obs_u8, const float* Wc, const float* b
 
 }  // namespace flm
 
-// K slices of the first dense layer (advantage and value streams side by side: 8 column tiles).  Two
-// workgroups of the split-operand kernel fit a CU, 512 on the chip, and a launch takes as long as its fullest
-// CUs: the number of slices n is the one with the least estimated time, rounds(n) / n of a pass over the whole K
-// (rounds = launches' workgroups over 512, rounded up) plus n partial sums to write and reduce (about a millionth of
-// a pass per sample and slice).  512 samples: 16 slices, one round; 2,250 (a rollout step of 1024 x 10): 7 slices, 1,008
-// workgroups, instead of 3 slices that leave 80 CUs with one workgroup (measured: 0.527 against 0.553 ms per forward).
-static int fc1_k_slices(int B) {
+// K slices of the first dense layer (advantage and value streams side by side: 8 column tiles).
+// fc1_k_slices_cap(B): the most slices a batch of B rows is ever given - what workspaces are sized for: the count with
+// the least rounds(n) / n of a pass over K (rounds = the launch's workgroups over the 512 that fit the chip, rounded up)
+// plus n partial sums to write and reduce.
+static int fc1_k_slices_cap(int B) {
   const long tiles = (long)((B + GBM - 1) / GBM) * 8;
   int best = 1;
   double best_cost = 0;
   for (int n = 1; n <= 32; n++) {
     const double cost = (double)((tiles * n + 511) / 512) / n + n * (double)B * 1e-6;
+    if (n == 1 || cost < best_cost) {
+      best = n;
+      best_cost = cost;
+    }
+  }
+  return best;
+}
+
+// The slices used for a product over K columns: a launch takes as long as its fullest CU, and a CU works its
+// workgroups off at one rate whether one or two are resident, so the estimate is, in units of one k of one tile,
+// ceil(workgroups / 256) * (K / n + 30) for the products and each workgroup's start and end, plus 0.028 * n * B for
+// the partial sums.  Measured points it reproduces (forward over 20 of 70 rails, K = 3,840): 512 rows 8 slices
+// (74 us; 16: 78, 4: 87), 1,024 rows 4 (97; 8: 99, 2: 123), 2,250 rows 3 or 7 (186, 188; 4: 195, 2: 220).
+static int fc1_k_slices(int B, long K) {
+  const long tiles = (long)((B + GBM - 1) / GBM) * 8;
+  const int cap = fc1_k_slices_cap(B);
+  int best = 1;
+  double best_cost = 0;
+  for (int n = 1; n <= cap; n++) {
+    const double cost = (double)((tiles * n + 255) / 256) * ((double)K / n + 30.0) + 0.028 * n * (double)B;
     if (n == 1 || cost < best_cost) {
       best = n;
       best_cost = cost;
@@ -1638,7 +1658,7 @@ extern "C" long flm_dqn_param_count(int H3, int T1, int NA) { return actions_ok(
 
 // workspace floats needed by flm_dqn_forward for a batch of B samples
 extern "C" long flm_dqn_forward_workspace(int B, int H3) {
-  return (long)B * 64 * H3 + (long)B * 1024 + (long)fc1_k_slices(B) * B * 1024 + 1024;   // x1, hid, K slices, a bias vector
+  return (long)B * 64 * H3 + (long)B * 1024 + (long)fc1_k_slices_cap(B) * B * 1024 + 1024;   // x1, hid, K slices, a bias vector
 }
 
 // small batches (act): the first dense layer streams both weight matrices in one launch
@@ -1708,7 +1728,7 @@ static int dqn_conv_stage(const float* params, const float* x, const uint8_t* ob
 }
 
 // The dense layers behind the convolution: hid[B,1024] and q[B,NA] from x1[B,64*H3]; part is workspace for the K
-// slices of the first dense layer (fc1_k_slices(B) * B * 1024 floats).
+// slices of the first dense layer (fc1_k_slices_cap(B) * B * 1024 floats).
 static int dqn_dense_stage(const float* params, int B, int H3, int T1, int NA, const float* x1, float* hid, float* part,
                            float* q, hipStream_t stream) {
   DqnLayout L(H3, T1, NA);
@@ -1735,7 +1755,7 @@ static int dqn_dense_stage(const float* params, int B, int H3, int T1, int NA, c
   } else {
     // K = 64*H3 is long and M x N small: split K over workgroups, then reduce with bias + ReLU.  Both streams
     // in one launch: group 0 = advantage, group 1 = value (their weight blocks are a fixed stride apart).
-    const int nks = fc1_k_slices(B);
+    const int nks = fc1_k_slices(B, L.K1);
     const int ks = (int)(((L.K1 + nks - 1) / nks + XBK - 1) / XBK * XBK);
     g = GemmArgs{};
     g.A = x1; g.B = params + L.a1_w; g.C = part;
@@ -1790,7 +1810,7 @@ static int dqn_dense_stage_rails(const float* params, int B, int Rp, int R4, int
   hipLaunchKernelGGL(flm::fc1_padding_bias_kernel, dim3(1024), dim3(256), 0, stream, params + L.a1_w, params + L.v1_w,
                      params + L.a1_b, params + L.v1_b, params + L.conv_b, L.K1, H3, Rp, R4, bias2, wpad_out);
   const long Kc = 192L * R4;
-  const int nks = fc1_k_slices(B);
+  const int nks = fc1_k_slices(B, Kc);
   const int ks = (int)(((Kc + nks - 1) / nks + XBK - 1) / XBK * XBK);
   GemmArgs g{};
   g.A = x1c; g.B = params + L.a1_w; g.C = part;
@@ -1852,7 +1872,7 @@ extern "C" int flm_dqn_forward_u8_rails(const float* params, const uint8_t* obs,
   float* x1c = workspace;                                   // (the layout of flm_dqn_forward_u8: the compact x1 is smaller)
   float* hid = workspace + (long)n * 64 * H3;
   float* part = hid + (long)n * 1024;
-  float* bias2 = part + (long)fc1_k_slices(n) * n * 1024;
+  float* bias2 = part + (long)fc1_k_slices_cap(n) * n * 1024;
   return dqn_forward_rails(params, obs, plane_stride, n, Rp, R4, T1, NA, x1c, hid, part, bias2, q, (hipStream_t)stream);
 }
 
@@ -1869,7 +1889,7 @@ extern "C" int flm_obs_to_f32(const uint8_t* obs, int n, int Rp, int T1, int pla
 
 // split-K partials of a learn step: the local network's two forward passes run as one batch of 2B
 static long learn_part_floats(int B) {
-  const long one = (long)fc1_k_slices(B) * B * 1024, two = (long)fc1_k_slices(2 * B) * 2 * B * 1024;
+  const long one = (long)fc1_k_slices_cap(B) * B * 1024, two = (long)fc1_k_slices_cap(2 * B) * 2 * B * 1024;
   return one > two ? one : two;
 }
 
@@ -1999,20 +2019,21 @@ static int learn_dense_half(const float* local, const float* target, const float
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   // first dense layer: weight gradients dW[n,j] = sum_b dhid[b,n] * x1[b,j], both streams as two groups of one launch
   // (more workgroups per launch: fewer idle matrix pipes in the last round); bias gradients = column sums
+  // (a copy of the sums in the workspace for the used-rails form: a data-parallel caller may be reducing grads by the
+  // time the second half reads them)
   hipLaunchKernelGGL(flm::colsum_kernel, dim3(16), dim3(1024), 0, stream, w.dhid, B, 1024, 1024L, grads + L.a1_b, 512,
-                     grads + L.v1_b);
+                     grads + L.v1_b, R4 ? w.gsum : (float*)nullptr);
   GemmArgs g{};
   g.A = w.dhid; g.B = w.x1; g.C = grads + L.a1_w;
   g.M = 512; g.N = (int)L.K1; g.K = B; g.lda = 1024; g.ldb = L.K1; g.ldc = L.K1;
   g.ksplit = B; g.groups = 2; g.a_zs = 512; g.b_zs = 0; g.c_zs = 0; g.c_gs = L.v1_w - L.a1_w; g.x_slowest = 1;
   if (R4) {
     // over the used rails: the columns of the product are scattered into the rows of dW, the rest of dW is filled from
-    // the column sums (a copy of them in the workspace: a data-parallel caller may be reducing grads by then)
+    // the column sums
     const long Kc = 192L * R4;
     g.N = (int)Kc; g.ldb = Kc;
     g.b_seg_len = R4; g.b_seg_stride = Rp; g.b_seg_magic = (unsigned)((0x100000000ULL + (unsigned)R4 - 1) / (unsigned)R4);
     if ((rc = flm::launch_gemm<false, false, flm::EPI_PLAIN, 3>(g, 2, stream))) return rc;
-    hipLaunchKernelGGL(flm::colsum_kernel, dim3(16), dim3(1024), 0, stream, w.dhid, B, 1024, 1024L, w.gsum, 512, w.gsum + 512);
     hipLaunchKernelGGL(flm::fc1_wgrad_padding_kernel, dim3(1024), dim3(256), 0, stream, w.gsum, local + L.conv_b,
                        grads + L.a1_w, grads + L.v1_w, L.K1, H3, Rp, R4);
   } else {
