@@ -59,7 +59,10 @@ _SIGNATURES = {
     "flm_dqn_learn_grads_phase": [_p, _p, _p, _p, _p, _p, _p, C.c_float, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p],
     "flm_dqn_learn_grads_u8_phase": [_p, _p, _p, _p, _i, _p, _p, _p, C.c_float, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p],
     "flm_dqn_learn_rails": [_i, _i, _i, _i],
-    "flm_dqn_learn_grads_u8_rails": [_p, _p, _p, _p, _i, _p, _p, _p, C.c_float, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p],
+    "flm_dqn_learn_grads_u8_rails": [_p, _p, _p, _p, _i, _p, _p, _p, C.c_float, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p],
+    "flm_dqn_learn_rails_rcb_offset": [_i, _i, _i, _i],
+    "flm_dqn_adam_soft_update_rails": [_p, _p, _p, _p, _p, C.c_long, C.c_double, C.c_double, C.c_double, C.c_double, _i,
+                                       C.c_double, _i, _i, _i, _i, _p, _p],
     "flm_dqn_forward": [_p, _p, _i, _i, _i, _i, _p, _p, _p],
     "flm_obs_to_f32": [_p, _i, _i, _i, _i, _p, _p],
     "flm_dqn_forward_u8": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
@@ -79,7 +82,7 @@ _SIGNATURES = {
                                  C.c_double, _p],
 }
 
-_LONG_RESULT = {"flm_paths_columns_lds_bytes", "flm_paths_columns_workspace", "flm_dqn_param_count", "flm_dqn_grad_split", "flm_dqn_learn_rails", "flm_replay_store_slots_workspace", "flm_dqn_forward_workspace", "flm_dqn_learn_workspace",
+_LONG_RESULT = {"flm_paths_columns_lds_bytes", "flm_paths_columns_workspace", "flm_dqn_param_count", "flm_dqn_grad_split", "flm_dqn_learn_rails", "flm_dqn_learn_rails_rcb_offset", "flm_replay_store_slots_workspace", "flm_dqn_forward_workspace", "flm_dqn_learn_workspace",
                 "flm_dqn_learn_workspace_u8"}
 _lib = None
 

@@ -41,15 +41,22 @@ class FlatAdam:
         self._ensure()
         self.grads.zero_()
 
-    def step(self, target=None, tau=None):
+    def step(self, target=None, tau=None, rails=None):
         """One Adam step; with target (the target network's flat parameters) and tau also its soft update with
-        the new parameters, in the same pass."""
+        the new parameters, in the same pass.  rails = (Rp, T1, NA, rails4, rcb): the learn step ran over the used
+        rails and left the first dense layer's gradient under the empty rows to this pass
+        (flm_dqn_adam_soft_update_rails)."""
         flat = self._ensure()
         self.step_count += 1
         st = torch.cuda.current_stream(flat.device).cuda_stream
         if target is None:
             call("flm_dqn_adam", ptr(flat), ptr(self.grads), ptr(self.m), ptr(self.v), flat.numel(), float(self.lr),
                  float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_count, st)
+        elif rails is not None:
+            Rp, T1, NA, rails4, rcb = rails
+            call("flm_dqn_adam_soft_update_rails", ptr(flat), ptr(self.grads), ptr(self.m), ptr(self.v), ptr(target),
+                 flat.numel(), float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                 self.step_count, float(tau), int(Rp), int(T1), int(NA), int(rails4), ptr(rcb), st)
         else:
             call("flm_dqn_adam_soft_update", ptr(flat), ptr(self.grads), ptr(self.m), ptr(self.v), ptr(target),
                  flat.numel(), float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
@@ -150,12 +157,22 @@ class DQNAgent:
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         self.optimizer._ensure()                            # (no zero_grad: the kernels write every gradient element)
         st = torch.cuda.current_stream(dev).cuda_stream
+        # over the used rails the gradient under the empty rows is a product the optimizer pass can form itself: it is
+        # then neither written nor read (only with this class's own optimizer step and soft update, and while the
+        # weight blocks' indices stay below 2^24)
+        rails4 = query("flm_dqn_learn_rails", B, Rp, self.width, int(rails_used))
+        fused = rails4 > 0 and type(self).soft_update is DQNAgent.soft_update and 512 * 64 * self.height < (1 << 24)
         args = (ptr(local), ptr(target), ptr(s), ptr(sn), int(plane_stride), ptr(a), ptr(r), ptr(d),
                 float(gamma), 1 if self.double_dqn else 0, B, Rp, self.width, self.action_space, int(rails_used),
-                ptr(self._ws), ptr(self.optimizer.grads), ptr(loss))
+                ptr(self._ws), ptr(self.optimizer.grads), ptr(loss), 0 if fused else 1)
         self._grads_and_exchange("flm_dqn_learn_grads_u8_rails", args, st, phased_entry=True)
         self.last_loss = loss
-        self._update(target)
+        if fused:
+            off = query("flm_dqn_learn_rails_rcb_offset", B, Rp, self.width, self.action_space)
+            self.optimizer.step(target=target, tau=self.args.tau,
+                                rails=(Rp, self.width, self.action_space, rails4, self._ws[off:off + 64]))
+        else:
+            self._update(target)
 
     def _grads_and_exchange(self, entry, args, stream, phased_entry=False):
         """The gradients of one learn step and, with several ranks, their average over the ranks (the reference is a

@@ -685,7 +685,8 @@ __global__ __launch_bounds__(64) void head_forward_kernel(const float* __restric
 __global__ __launch_bounds__(256) void fc1_padding_bias_kernel(const float* __restrict__ Wa, const float* __restrict__ Wv,
                                                                const float* __restrict__ bias_a, const float* __restrict__ bias_v,
                                                                const float* __restrict__ conv_b, long K1, int H3, int Rp, int R4,
-                                                               float* __restrict__ bias2, float* __restrict__ wpad_out) {
+                                                               float* __restrict__ bias2, float* __restrict__ wpad_out,
+                                                               float* __restrict__ rcb_out) {
   __shared__ float lane_sum[64][65];
   __shared__ float red[64];
   const int o = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -710,6 +711,7 @@ __global__ __launch_bounds__(256) void fc1_padding_bias_kernel(const float* __re
     float wp = 0.f;
     for (int l = 0; l < 64; l++) wp += lane_sum[t][l];
     if (wpad_out) wpad_out[(long)t * 1024 + o] = wp;             // [filter][output unit]
+    if (rcb_out && o == 0) rcb_out[t] = fmaxf(conv_b[t], 0.f);   // what every filter gives on an empty row
     red[t] = fmaxf(conv_b[t], 0.f) * wp;
   }
   __syncthreads();
@@ -976,6 +978,48 @@ __global__ void adam_soft_update_kernel(float* __restrict__ p, const float* __re
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float gi = g[i];
+  const float mi = __fadd_rn(m[i], __fmul_rn(one_minus_b1, __fsub_rn(gi, m[i])));
+  const float vi = __fadd_rn(__fmul_rn(v[i], beta2), __fmul_rn(__fmul_rn(one_minus_b2, gi), gi));
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2_sqrt), eps);
+  const float pi = __fadd_rn(p[i], __fmul_rn(-step_size, __fdiv_rn(mi, denom)));
+  p[i] = pi;
+  target[i] = __fadd_rn(__fmul_rn(tau, pi), __fmul_rn(one_minus_tau, target[i]));
+}
+
+// The same pass after a learn step over the used rails that left the first dense layer's weight gradient under the
+// empty rows unwritten: there it is rcb[c] * g[bias of o] (fc1_wgrad_padding_kernel's product), taken from the layer's
+// bias gradient instead of being read - 39 MB less to write and to read at 20 of 70 rails.  Indices of the two weight
+// blocks are below 2^24: the quotients come from float estimates corrected by one.
+__device__ __forceinline__ unsigned div_small(unsigned n, unsigned d, float inv_d) {
+  unsigned q = (unsigned)((float)n * inv_d);
+  if (q * d > n) q--;
+  else if ((q + 1) * d <= n) q++;
+  return q;
+}
+__global__ void adam_soft_update_rails_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, float* __restrict__ target, long n, float one_minus_b1,
+                                              float beta2, float one_minus_b2, float eps, float step_size, float bc2_sqrt,
+                                              float tau, float one_minus_tau, long a1_w, long a1_b, long v1_w, long v1_b,
+                                              unsigned K1, unsigned H3, unsigned Rp, unsigned R4, float inv_K1, float inv_H3,
+                                              float inv_Rp, const float* __restrict__ rcb) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float gi;
+  const bool adv = i >= a1_w && i < a1_b, val = i >= v1_w && i < v1_b;
+  bool synth = false;
+  if (adv || val) {
+    const unsigned j = (unsigned)(i - (adv ? a1_w : v1_w));
+    const unsigned o = div_small(j, K1, inv_K1), rem = j - o * K1;
+    const unsigned c = div_small(rem, H3, inv_H3), r2 = rem - c * H3;
+    const unsigned rail = r2 - div_small(r2, Rp, inv_Rp) * Rp;
+    if (rail >= R4) {
+      synth = true;
+      gi = __fmul_rn(rcb[c], g[(adv ? a1_b : v1_b) + o]);
+    }
+  }
+  if (!synth) gi = g[i];
   const float mi = __fadd_rn(m[i], __fmul_rn(one_minus_b1, __fsub_rn(gi, m[i])));
   const float vi = __fadd_rn(__fmul_rn(v[i], beta2), __fmul_rn(__fmul_rn(one_minus_b2, gi), gi));
   m[i] = mi;
@@ -1803,12 +1847,13 @@ static int dqn_rails_used(int B, int Rp, int rails_used) {
 // The dense layers behind a convolution over the used rails: x1c [B,64,3*R4] -> hid, q.  bias2: 1024 floats of
 // workspace; wpad_out: 1024*64 floats or nullptr (fc1_padding_bias_kernel).
 static int dqn_dense_stage_rails(const float* params, int B, int Rp, int R4, int T1, int NA, const float* x1c, float* hid,
-                                 float* part, float* bias2, float* wpad_out, float* q, hipStream_t stream) {
+                                 float* part, float* bias2, float* wpad_out, float* q, hipStream_t stream,
+                                 float* rcb_out = nullptr) {
   const int H3 = 3 * Rp;
   DqnLayout L(H3, T1, NA);
   int rc;
   hipLaunchKernelGGL(flm::fc1_padding_bias_kernel, dim3(1024), dim3(256), 0, stream, params + L.a1_w, params + L.v1_w,
-                     params + L.a1_b, params + L.v1_b, params + L.conv_b, L.K1, H3, Rp, R4, bias2, wpad_out);
+                     params + L.a1_b, params + L.v1_b, params + L.conv_b, L.K1, H3, Rp, R4, bias2, wpad_out, rcb_out);
   const long Kc = 192L * R4;
   const int nks = fc1_k_slices(B, Kc);
   const int ks = (int)(((Kc + nks - 1) / nks + XBK - 1) / XBK * XBK);
@@ -1911,7 +1956,7 @@ extern "C" long flm_dqn_learn_workspace(int B, int H3, int T1, int NA) {
          + learn_cpart_floats(B, T1)                          // conv weight-gradient partials
          + learn_part_floats(B)                               // split-K partials of the first dense layer
          + (((5L * NA + 2) * B + 64 + 3) & ~3L)               // three q's, dq, dadv; dval, squared errors (whole 16 bytes)
-         + 2 * 1024 + 1024 * 64 + 1024;                       // used-rails form: two bias vectors, wpad, column sums of dhid
+         + 2 * 1024 + 1024 * 64 + 1024 + 64;                  // used-rails form: two bias vectors, wpad, column sums of dhid, relu(conv bias)
 }
 
 // Forward passes, loss and backward of one learn step (src/agent.py:94-114); grads gets dLoss/dparams of
@@ -1925,7 +1970,7 @@ extern "C" long flm_dqn_learn_workspace(int B, int H3, int T1, int NA) {
 // gradients (the floats before the split).  A data-parallel caller sends the first part on its way between the two.
 struct LearnWorkspace {
   float *x1, *hid, *x1n, *hidn, *x1t, *hidt, *dhid, *dx1, *cpart, *part, *q, *qn, *qt, *dq, *dadv, *dval, *sq;
-  float *bias2, *wpad, *gsum;   // used-rails form
+  float *bias2, *wpad, *gsum, *rcb;   // used-rails form
   LearnWorkspace(float* ws, int B, int H3, int T1, int NA) {
     // x1 / x1n, hid / hidn and q / qn are adjacent: the local network sees [s; s'] as one batch of 2B
     const long n_x1 = (long)B * 64 * H3, n_hid = (long)B * 1024;
@@ -1942,13 +1987,15 @@ struct LearnWorkspace {
     bias2 = q + (((5L * NA + 2) * B + 64 + 3) & ~3L);
     wpad = bias2 + 2 * 1024;
     gsum = wpad + 1024 * 64;
+    rcb = gsum + 1024;
   }
 };
 
 static int learn_dense_half(const float* local, const float* target, const float* s, const float* s_next,
                             const uint8_t* s_u8, const uint8_t* sn_u8, int plane_stride, const int64_t* action,
                             const float* reward, const float* done, float gamma, int double_dqn, int B, int H3, int T1,
-                            int NA, const LearnWorkspace& w, float* grads, float* loss_out, hipStream_t stream, int R4 = 0) {
+                            int NA, const LearnWorkspace& w, float* grads, float* loss_out, hipStream_t stream, int R4 = 0,
+                            int fill_padding = 1) {
   DqnLayout L(H3, T1, NA);
   int rc;
   // R4 > 0 (uint8 observations only): rails [R4, Rp) are empty in every plane of every observation; the convolutions and
@@ -1986,7 +2033,8 @@ static int learn_dense_half(const float* local, const float* target, const float
   }
   const int n_local = double_dqn ? 2 * B : B;
   if (R4) {
-    if ((rc = dqn_dense_stage_rails(local, n_local, Rp, R4, T1, NA, w.x1, w.hid, w.part, w.bias2, w.wpad, w.q, stream))) return rc;
+    if ((rc = dqn_dense_stage_rails(local, n_local, Rp, R4, T1, NA, w.x1, w.hid, w.part, w.bias2, w.wpad, w.q, stream, w.rcb)))
+      return rc;
     if (!target_conv_done && (rc = dqn_conv_stage(target, nullptr, sn_u8, plane_stride, B, H3c, T1, NA, w.x1t, stream))) return rc;
     rc = dqn_dense_stage_rails(target, B, Rp, R4, T1, NA, w.x1t, w.hidt, w.part, w.bias2 + 1024, nullptr, w.qt, stream);
   } else {
@@ -2034,8 +2082,9 @@ static int learn_dense_half(const float* local, const float* target, const float
     g.N = (int)Kc; g.ldb = Kc;
     g.b_seg_len = R4; g.b_seg_stride = Rp; g.b_seg_magic = (unsigned)((0x100000000ULL + (unsigned)R4 - 1) / (unsigned)R4);
     if ((rc = flm::launch_gemm<false, false, flm::EPI_PLAIN, 3>(g, 2, stream))) return rc;
-    hipLaunchKernelGGL(flm::fc1_wgrad_padding_kernel, dim3(1024), dim3(256), 0, stream, w.gsum, local + L.conv_b,
-                       grads + L.a1_w, grads + L.v1_w, L.K1, H3, Rp, R4);
+    if (fill_padding)     // (otherwise the optimizer pass forms these products itself: flm_dqn_adam_soft_update_rails)
+      hipLaunchKernelGGL(flm::fc1_wgrad_padding_kernel, dim3(1024), dim3(256), 0, stream, w.gsum, local + L.conv_b,
+                         grads + L.a1_w, grads + L.v1_w, L.K1, H3, Rp, R4);
   } else {
     if ((rc = flm::launch_gemm<false, false, flm::EPI_PLAIN>(g, 2, stream))) return rc;
   }
@@ -2117,12 +2166,13 @@ static int learn_conv_half(const float* local, const float* s, const uint8_t* s_
 static int learn_grads_impl(const float* local, const float* target, const float* s, const float* s_next,
                             const uint8_t* s_u8, const uint8_t* sn_u8, int plane_stride, const int64_t* action,
                             const float* reward, const float* done, float gamma, int double_dqn, int B, int H3, int T1,
-                            int NA, float* ws, float* grads, float* loss_out, hipStream_t stream, int phase = 0, int R4 = 0) {
+                            int NA, float* ws, float* grads, float* loss_out, hipStream_t stream, int phase = 0, int R4 = 0,
+                            int fill_padding = 1) {
   const LearnWorkspace w(ws, B, H3, T1, NA);
   int rc = FLM_OK;
   if (phase != 2)
     rc = learn_dense_half(local, target, s, s_next, s_u8, sn_u8, plane_stride, action, reward, done, gamma, double_dqn, B, H3,
-                          T1, NA, w, grads, loss_out, stream, R4);
+                          T1, NA, w, grads, loss_out, stream, R4, fill_padding);
   if (rc == FLM_OK && phase != 1) rc = learn_conv_half(local, s, s_u8, plane_stride, B, H3, T1, NA, w, grads, stream, R4);
   return rc;
 }
@@ -2190,7 +2240,8 @@ extern "C" long flm_dqn_learn_rails(int B, int Rp, int T1, int rails_used) {
 extern "C" int flm_dqn_learn_grads_u8_rails(const float* local, const float* target, const uint8_t* s, const uint8_t* s_next,
                                             int plane_stride, const int64_t* action, const float* reward, const float* done,
                                             float gamma, int double_dqn, int B, int Rp, int T1, int NA, int rails_used,
-                                            float* ws, float* grads, float* loss_out, int phase, void* stream) {
+                                            float* ws, float* grads, float* loss_out, int fill_padding, int phase,
+                                            void* stream) {
   if (!local || !target || !s || !s_next || !action || !reward || !done || !ws || !grads || !loss_out) return FLM_E_ARG;
   if (B <= 0 || Rp <= 0 || T1 <= 0 || (long)plane_stride < (long)Rp * T1 || !actions_ok(NA) || phase < 0 || phase > 2 ||
       rails_used < 0 || rails_used > Rp)
@@ -2200,7 +2251,7 @@ extern "C" int flm_dqn_learn_grads_u8_rails(const float* local, const float* tar
   const int R4 = (int)flm_dqn_learn_rails(B, Rp, T1, rails_used);
   float* s_f32 = ws + flm_dqn_learn_workspace(B, H3, T1, NA);
   return learn_grads_impl(local, target, s_f32, nullptr, s, s_next, plane_stride, action, reward, done, gamma, double_dqn, B,
-                          H3, T1, NA, ws, grads, loss_out, (hipStream_t)stream, phase, R4);
+                          H3, T1, NA, ws, grads, loss_out, (hipStream_t)stream, phase, R4, fill_padding);
 }
 
 extern "C" int flm_dqn_adam(float* params, const float* grads, float* m, float* v, long n, double lr, double beta1,
@@ -2224,6 +2275,33 @@ extern "C" int flm_dqn_adam_soft_update(float* params, const float* grads, float
   hipLaunchKernelGGL(flm::adam_soft_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      params, grads, m, v, target, n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
                      (float)(lr / bc1), (float)sqrt(bc2), (float)tau, (float)(1.0 - tau));
+  if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
+  return FLM_OK;
+}
+
+// float offset, inside the workspace of flm_dqn_learn_grads_u8_rails, of the 64 values relu(conv bias) the step left
+// there (what flm_dqn_adam_soft_update_rails needs of it)
+extern "C" long flm_dqn_learn_rails_rcb_offset(int B, int Rp, int T1, int NA) {
+  if (B <= 0 || Rp <= 0 || T1 <= 0 || !actions_ok(NA)) return -1;
+  float* base = nullptr;
+  const LearnWorkspace w(base, B, 3 * Rp, T1, NA);
+  return (long)(w.rcb - base);
+}
+
+extern "C" int flm_dqn_adam_soft_update_rails(float* params, const float* grads, float* m, float* v, float* target, long n,
+                                              double lr, double beta1, double beta2, double eps, int step, double tau, int Rp,
+                                              int T1, int NA, int rails4, const float* rcb, void* stream) {
+  if (!params || !grads || !m || !v || !target || !rcb || n <= 0 || step <= 0 || Rp <= 0 || T1 <= 0 || !actions_ok(NA))
+    return FLM_E_ARG;
+  const DqnLayout L(3 * Rp, T1, NA);
+  if (n != L.total || rails4 <= 0 || rails4 >= Rp || (rails4 & 3) || 512L * L.K1 >= (1L << 24)) return FLM_E_ARG;
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  hipLaunchKernelGGL(flm::adam_soft_update_rails_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     params, grads, m, v, target, n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                     (float)(lr / bc1), (float)sqrt(bc2), (float)tau, (float)(1.0 - tau), L.a1_w, L.a1_b, L.v1_w, L.v1_b,
+                     (unsigned)L.K1, (unsigned)(3 * Rp), (unsigned)Rp, (unsigned)rails4, 1.0f / (float)L.K1,
+                     1.0f / (float)(3 * Rp), 1.0f / (float)Rp, rcb);
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
 }

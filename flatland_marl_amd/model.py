@@ -28,7 +28,9 @@ class Dueling_DQN(nn.Module):
     # ---- flat parameter buffer -------------------------------------------------------------------------
     def flat_params(self):
         """One contiguous fp32 device buffer; the module's parameters are views into it."""
-        params = list(self.parameters())
+        # (self.parameters() in registration order, without the module walk: this runs several times per learn step)
+        params = [self.conv1.weight, self.conv1.bias, self.fc1_adv.weight, self.fc1_adv.bias, self.fc1_val.weight,
+                  self.fc1_val.bias, self.fc2_adv.weight, self.fc2_adv.bias, self.fc2_val.weight, self.fc2_val.bias]
         dev = params[0].device
         if dev.type != "cuda":
             raise _lib.FlmError("Dueling_DQN must live on a GPU (call .to('cuda')): there is no CPU forward")

@@ -461,7 +461,8 @@ int flm_dqn_learn_grads_u8_phase(const float* local, const float* target, const 
                                  float gamma, int double_dqn, int B, int Rp, int T1, int NA, float* workspace,
                                  float* grads, float* loss_out, int phase, void* stream);
 
-/* flm_dqn_learn_grads_u8 (phase 0) or one half of it (phase 1 / 2, as flm_dqn_learn_grads_u8_phase) for observations
+/* flm_dqn_learn_grads_u8 (phase 0) or one half of it (phase 1 / 2, as flm_dqn_learn_grads_u8_phase; fill_padding = 1:
+ * see below) for observations
  * whose rails [rails_used, Rp) are empty in every plane, states and next states alike (see flm_dqn_forward_u8_rails).
  * Forward passes and the products of the backward pass run over the used rails only; what the empty rails contribute
  * is added in closed form: to the first dense layer's pre-activations a vector per network, to its weight gradient
@@ -474,7 +475,19 @@ long flm_dqn_learn_rails(int B, int Rp, int T1, int rails_used);   /* rails per 
 int flm_dqn_learn_grads_u8_rails(const float* local, const float* target, const uint8_t* s, const uint8_t* s_next,
                                  int plane_stride, const int64_t* action, const float* reward, const float* done,
                                  float gamma, int double_dqn, int B, int Rp, int T1, int NA, int rails_used,
-                                 float* workspace, float* grads, float* loss_out, int phase, void* stream);
+                                 float* workspace, float* grads, float* loss_out, int fill_padding, int phase,
+                                 void* stream);
+
+/* fill_padding = 0 (only when flm_dqn_learn_rails(...) > 0): the first dense layer's weight gradient under the empty
+ * rows is left unwritten - it is relu(conv bias[c]) times the layer's bias gradient, and flm_dqn_adam_soft_update_rails
+ * forms it from the bias gradient in `grads` (after any averaging over ranks) and from the 64 values relu(conv bias)
+ * that the learn step left in its workspace at float offset flm_dqn_learn_rails_rcb_offset(...): the same update as
+ * flm_dqn_adam_soft_update after a step with fill_padding = 1, without writing and reading those products.
+ * rails4 = flm_dqn_learn_rails(...); n = flm_dqn_param_count(3*Rp, T1, NA); 512 * 64 * 3 * Rp < 2^24. */
+long flm_dqn_learn_rails_rcb_offset(int B, int Rp, int T1, int NA);
+int flm_dqn_adam_soft_update_rails(float* params, const float* grads, float* m, float* v, float* target, long n, double lr,
+                                   double beta1, double beta2, double eps, int step, double tau, int Rp, int T1, int NA,
+                                   int rails4, const float* rcb, void* stream);
 
 /* Uniform sampling without replacement from a replay memory that lives in device memory, and the gather of the
  * sampled transitions.  Replaces ReplayBuffer.sample, src/agent.py:159-174 (random.sample over the deque, then

@@ -753,7 +753,7 @@ def test_learn_over_the_used_rails_matches_the_plain_learn_step(Rp, T1, B, rails
     want, loss_w = torch.zeros(n, device="cuda"), torch.zeros(1, device="cuda")
     call("flm_dqn_learn_grads_u8", *head(both[:B], both[B:]), ptr(ws), ptr(want), ptr(loss_w), st)
     got, loss_g = torch.zeros(n, device="cuda"), torch.zeros(1, device="cuda")
-    call("flm_dqn_learn_grads_u8_rails", *head(both[:B], both[B:]), rails, ptr(ws), ptr(got), ptr(loss_g), 0, st)
+    call("flm_dqn_learn_grads_u8_rails", *head(both[:B], both[B:]), rails, ptr(ws), ptr(got), ptr(loss_g), 1, 0, st)
     torch.cuda.synchronize()
     assert torch.allclose(loss_g, loss_w, rtol=1e-5)
     shapes = [(64, T1), (64,), (512, 64, 3, Rp), (512,), (512, 64, 3, Rp), (512,), (2, 512), (2,), (1, 512), (1,)]
@@ -771,12 +771,35 @@ def test_learn_over_the_used_rails_matches_the_plain_learn_step(Rp, T1, B, rails
     assert off == n and want.abs().max().item() > 0
     # two phases: the same bits as the one call
     two, loss_t = torch.full((n,), 7.0, device="cuda"), torch.zeros(1, device="cuda")
-    call("flm_dqn_learn_grads_u8_rails", *head(both[:B], both[B:]), rails, ptr(ws), ptr(two), ptr(loss_t), 1, st)
-    call("flm_dqn_learn_grads_u8_rails", *head(both[:B], both[B:]), rails, ptr(ws), ptr(two), ptr(loss_t), 2, st)
+    call("flm_dqn_learn_grads_u8_rails", *head(both[:B], both[B:]), rails, ptr(ws), ptr(two), ptr(loss_t), 1, 1, st)
+    call("flm_dqn_learn_grads_u8_rails", *head(both[:B], both[B:]), rails, ptr(ws), ptr(two), ptr(loss_t), 1, 2, st)
     # next states apart from the states: the same bits again
     s_apart, sn_apart = both[:B].clone(), both[B:].clone()
     apart, loss_a = torch.zeros(n, device="cuda"), torch.zeros(1, device="cuda")
-    call("flm_dqn_learn_grads_u8_rails", *head(s_apart, sn_apart), rails, ptr(ws), ptr(apart), ptr(loss_a), 0, st)
+    call("flm_dqn_learn_grads_u8_rails", *head(s_apart, sn_apart), rails, ptr(ws), ptr(apart), ptr(loss_a), 1, 0, st)
     torch.cuda.synchronize()
     assert torch.equal(two, got) and torch.equal(loss_t, loss_g)
     assert torch.equal(apart, got) and torch.equal(loss_a, loss_g)
+    # the gradient under the empty rows left to the optimizer pass: the same parameters, moments and target bit for bit
+    rails4 = query("flm_dqn_learn_rails", B, Rp, T1, rails)
+    if rails4:
+        m0 = torch.randn(n, generator=torch.Generator().manual_seed(3)).cuda() * 1e-3
+        v0 = torch.rand(n, generator=torch.Generator().manual_seed(4)).cuda() * 1e-6
+        outs = []
+        for fused in (False, True):
+            p_, t_, m_, v_ = local.clone(), target.clone(), m0.clone(), v0.clone()
+            gbuf = torch.full((n,), float("nan"), device="cuda")            # whatever is left unwritten must not be read
+            call("flm_dqn_learn_grads_u8_rails", ptr(p_), ptr(t_), ptr(both[:B]), ptr(both[B:]), ps, ptr(act), ptr(rew), ptr(done),
+                 0.97, ddqn, B, Rp, T1, 2, rails, ptr(ws), ptr(gbuf), ptr(loss_g), 0 if fused else 1, 0, st)
+            if fused:
+                off = query("flm_dqn_learn_rails_rcb_offset", B, Rp, T1, 2)
+                call("flm_dqn_adam_soft_update_rails", ptr(p_), ptr(gbuf), ptr(m_), ptr(v_), ptr(t_), n, 1e-3, 0.9, 0.999, 1e-8, 3,
+                     0.01, Rp, T1, 2, rails4, ptr(ws[off:off + 64]), st)
+            else:
+                assert not torch.isnan(gbuf).any()
+                call("flm_dqn_adam_soft_update", ptr(p_), ptr(gbuf), ptr(m_), ptr(v_), ptr(t_), n, 1e-3, 0.9, 0.999, 1e-8, 3, 0.01, st)
+            torch.cuda.synchronize()
+            outs.append((p_, t_, m_, v_))
+        for x, y in zip(*outs):
+            assert torch.equal(x, y)
+        assert not torch.equal(outs[0][0], local)
