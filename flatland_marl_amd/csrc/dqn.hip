@@ -956,18 +956,33 @@ __global__ __launch_bounds__(1024) void head_backward_params_kernel(const float*
 // ---- optimiser and target network --------------------------------------------------------------------
 // torch.optim.Adam defaults (no weight decay, no amsgrad), one step over the flat buffers.  The products
 // are kept unfused so that every intermediate is rounded where the tensor-by-tensor formulation rounds it.
+// One element of the step.  Contraction into fused multiply-adds is switched off here (the _rn intrinsics alone do not
+// prevent it), so that the three kernels below give the same bits whatever surrounds the call.
+struct AdamConsts { float one_minus_b1, beta2, one_minus_b2, eps, step_size, bc2_sqrt, tau, one_minus_tau; };
+__device__ __forceinline__ void adam_element(float& p, float g, float& m, float& v, const AdamConsts& k) {
+#pragma clang fp contract(off)
+  const float mi = m + k.one_minus_b1 * (g - m);
+  const float vi = v * k.beta2 + (k.one_minus_b2 * g) * g;
+  m = mi;
+  v = vi;
+  const float denom = __fdiv_rn(__fsqrt_rn(vi), k.bc2_sqrt) + k.eps;
+  p = p + (-k.step_size) * __fdiv_rn(mi, denom);
+}
+__device__ __forceinline__ float soft_element(float p, float t, const AdamConsts& k) {
+#pragma clang fp contract(off)
+  return k.tau * p + k.one_minus_tau * t;
+}
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n, float one_minus_b1, float beta2, float one_minus_b2, float eps, float step_size,
                             float bc2_sqrt) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float gi = g[i];
-  const float mi = __fadd_rn(m[i], __fmul_rn(one_minus_b1, __fsub_rn(gi, m[i])));
-  const float vi = __fadd_rn(__fmul_rn(v[i], beta2), __fmul_rn(__fmul_rn(one_minus_b2, gi), gi));
+  const AdamConsts k = {one_minus_b1, beta2, one_minus_b2, eps, step_size, bc2_sqrt, 0.f, 0.f};
+  float pi = p[i], mi = m[i], vi = v[i];
+  adam_element(pi, g[i], mi, vi, k);
   m[i] = mi;
   v[i] = vi;
-  const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2_sqrt), eps);
-  p[i] = __fadd_rn(p[i], __fmul_rn(-step_size, __fdiv_rn(mi, denom)));
+  p[i] = pi;
 }
 
 // Adam step followed by the soft update of the target network with the new parameters, in one pass
@@ -977,15 +992,13 @@ __global__ void adam_soft_update_kernel(float* __restrict__ p, const float* __re
                                         float tau, float one_minus_tau) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float gi = g[i];
-  const float mi = __fadd_rn(m[i], __fmul_rn(one_minus_b1, __fsub_rn(gi, m[i])));
-  const float vi = __fadd_rn(__fmul_rn(v[i], beta2), __fmul_rn(__fmul_rn(one_minus_b2, gi), gi));
+  const AdamConsts k = {one_minus_b1, beta2, one_minus_b2, eps, step_size, bc2_sqrt, tau, one_minus_tau};
+  float pi = p[i], mi = m[i], vi = v[i];
+  adam_element(pi, g[i], mi, vi, k);
   m[i] = mi;
   v[i] = vi;
-  const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2_sqrt), eps);
-  const float pi = __fadd_rn(p[i], __fmul_rn(-step_size, __fdiv_rn(mi, denom)));
   p[i] = pi;
-  target[i] = __fadd_rn(__fmul_rn(tau, pi), __fmul_rn(one_minus_tau, target[i]));
+  target[i] = soft_element(pi, target[i], k);
 }
 
 // The same pass after a learn step over the used rails that left the first dense layer's weight gradient under the
@@ -998,36 +1011,82 @@ __device__ __forceinline__ unsigned div_small(unsigned n, unsigned d, float inv_
   else if ((q + 1) * d <= n) q++;
   return q;
 }
-__global__ void adam_soft_update_rails_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                              float* __restrict__ v, float* __restrict__ target, long n, float one_minus_b1,
-                                              float beta2, float one_minus_b2, float eps, float step_size, float bc2_sqrt,
-                                              float tau, float one_minus_tau, long a1_w, long a1_b, long v1_w, long v1_b,
-                                              unsigned K1, unsigned H3, unsigned Rp, unsigned R4, float inv_K1, float inv_H3,
-                                              float inv_Rp, const float* __restrict__ rcb) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float gi;
-  const bool adv = i >= a1_w && i < a1_b, val = i >= v1_w && i < v1_b;
-  bool synth = false;
+__global__ __launch_bounds__(256) void adam_soft_update_rails_kernel(
+    float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+    float* __restrict__ target, long n, float one_minus_b1, float beta2, float one_minus_b2, float eps, float step_size,
+    float bc2_sqrt, float tau, float one_minus_tau, long a1_w, long a1_b, long v1_w, long v1_b, unsigned K1, unsigned H3,
+    unsigned Rp, unsigned R4, float inv_K1, float inv_H3, float inv_Rp, const float* __restrict__ rcb) {
+  // four consecutive parameters per thread (the two weight blocks start and end on multiples of four, so a thread's
+  // four lie inside one or outside both): their place (output unit, filter, rail) is worked out once and stepped
+  const long i0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i0 >= n) return;
+  const AdamConsts k = {one_minus_b1, beta2, one_minus_b2, eps, step_size, bc2_sqrt, tau, one_minus_tau};
+  const bool adv = i0 >= a1_w && i0 < a1_b, val = i0 >= v1_w && i0 < v1_b;
+  unsigned o = 0, c = 0, rail = 0, pl = 0;
   if (adv || val) {
-    const unsigned j = (unsigned)(i - (adv ? a1_w : v1_w));
-    const unsigned o = div_small(j, K1, inv_K1), rem = j - o * K1;
-    const unsigned c = div_small(rem, H3, inv_H3), r2 = rem - c * H3;
-    const unsigned rail = r2 - div_small(r2, Rp, inv_Rp) * Rp;
-    if (rail >= R4) {
-      synth = true;
-      gi = __fmul_rn(rcb[c], g[(adv ? a1_b : v1_b) + o]);
+    const unsigned j = (unsigned)(i0 - (adv ? a1_w : v1_w));
+    o = div_small(j, K1, inv_K1);
+    const unsigned rem = j - o * K1;
+    c = div_small(rem, H3, inv_H3);
+    const unsigned r2 = rem - c * H3;
+    pl = div_small(r2, Rp, inv_Rp);
+    rail = r2 - pl * Rp;
+  }
+  const float* gb = g + (adv ? a1_b : v1_b);
+  const bool whole = i0 + 3 < n;
+  float pv[4], mv[4], vv[4], tv[4], gv[4];
+  bool synth[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    synth[e] = (adv || val) && rail >= R4;
+    gv[e] = synth[e] ? rcb[c] * gb[o] : 0.f;
+    if (++rail == Rp) {
+      rail = 0;
+      if (++pl == 3) {
+        pl = 0;
+        if (++c == 64) { c = 0; o++; }
+      }
     }
   }
-  if (!synth) gi = g[i];
-  const float mi = __fadd_rn(m[i], __fmul_rn(one_minus_b1, __fsub_rn(gi, m[i])));
-  const float vi = __fadd_rn(__fmul_rn(v[i], beta2), __fmul_rn(__fmul_rn(one_minus_b2, gi), gi));
-  m[i] = mi;
-  v[i] = vi;
-  const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2_sqrt), eps);
-  const float pi = __fadd_rn(p[i], __fmul_rn(-step_size, __fdiv_rn(mi, denom)));
-  p[i] = pi;
-  target[i] = __fadd_rn(__fmul_rn(tau, pi), __fmul_rn(one_minus_tau, target[i]));
+  if (whole) {
+    const float4 p4 = *reinterpret_cast<const float4*>(p + i0), m4 = *reinterpret_cast<const float4*>(m + i0);
+    const float4 v4 = *reinterpret_cast<const float4*>(v + i0), t4 = *reinterpret_cast<const float4*>(target + i0);
+    pv[0] = p4.x; pv[1] = p4.y; pv[2] = p4.z; pv[3] = p4.w;
+    mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
+    vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
+    tv[0] = t4.x; tv[1] = t4.y; tv[2] = t4.z; tv[3] = t4.w;
+    if (!(synth[0] && synth[1] && synth[2] && synth[3])) {
+      const float4 g4 = *reinterpret_cast<const float4*>(g + i0);
+      if (!synth[0]) gv[0] = g4.x;
+      if (!synth[1]) gv[1] = g4.y;
+      if (!synth[2]) gv[2] = g4.z;
+      if (!synth[3]) gv[3] = g4.w;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+      if (i0 + e < n) {
+        pv[e] = p[i0 + e]; mv[e] = m[i0 + e]; vv[e] = v[i0 + e]; tv[e] = target[i0 + e];
+        if (!synth[e]) gv[e] = g[i0 + e];
+      } else {
+        pv[e] = mv[e] = vv[e] = tv[e] = gv[e] = 0.f;
+      }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    adam_element(pv[e], gv[e], mv[e], vv[e], k);
+    tv[e] = soft_element(pv[e], tv[e], k);
+  }
+  if (whole) {
+    *reinterpret_cast<float4*>(p + i0) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+    *reinterpret_cast<float4*>(m + i0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+    *reinterpret_cast<float4*>(v + i0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    *reinterpret_cast<float4*>(target + i0) = make_float4(tv[0], tv[1], tv[2], tv[3]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+      if (i0 + e < n) { p[i0 + e] = pv[e]; m[i0 + e] = mv[e]; v[i0 + e] = vv[e]; target[i0 + e] = tv[e]; }
+  }
 }
 
 // target <- tau*local + (1-tau)*target (src/agent.py:120-131)
@@ -1035,7 +1094,8 @@ __global__ void soft_update_kernel(float* __restrict__ target, const float* __re
                                    float one_minus_tau) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  target[i] = __fadd_rn(__fmul_rn(tau, local[i]), __fmul_rn(one_minus_tau, target[i]));
+  const AdamConsts k = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, tau, one_minus_tau};
+  target[i] = soft_element(local[i], target[i], k);
 }
 
 // uint8 observation planes (own plane is int8) -> fp32 rows [n, H3=3*Rp, T1]
@@ -2295,9 +2355,10 @@ extern "C" int flm_dqn_adam_soft_update_rails(float* params, const float* grads,
     return FLM_E_ARG;
   const DqnLayout L(3 * Rp, T1, NA);
   if (n != L.total || rails4 <= 0 || rails4 >= Rp || (rails4 & 3) || 512L * L.K1 >= (1L << 24)) return FLM_E_ARG;
+  if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v | (uintptr_t)target) & 15) return FLM_E_ARG;
   const double bc1 = 1.0 - pow(beta1, (double)step);
   const double bc2 = 1.0 - pow(beta2, (double)step);
-  hipLaunchKernelGGL(flm::adam_soft_update_rails_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(flm::adam_soft_update_rails_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream,
                      params, grads, m, v, target, n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
                      (float)(lr / bc1), (float)sqrt(bc2), (float)tau, (float)(1.0 - tau), L.a1_w, L.a1_b, L.v1_w, L.v1_b,
                      (unsigned)L.K1, (unsigned)(3 * Rp), (unsigned)Rp, (unsigned)rails4, 1.0f / (float)L.K1,
