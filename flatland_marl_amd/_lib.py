@@ -75,6 +75,8 @@ _SIGNATURES = {
                                _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "flm_replay_sample": [_i, _i, _u32, _u32, _p, _p],
     "flm_replay_gather": [_p, _p, _p, _p, _p, _p, _i, C.c_long, _p, _p, _p, _p, _p, _p],
+    "flm_replay_draw_gather": [_p, _p, _p, _p, _p, _i, _u32, _u32, _i, C.c_long, _i, C.c_long, C.c_long,
+                               _p, _p, _p, _p, _p, _p, _p],
     "flm_replay_gather_planes": [_p, _p, _p, _p, _p, _p, _i, C.c_long, _i, C.c_long, C.c_long, _p, _p, _p, _p, _p, _p],
     "flm_dqn_adam": [_p, _p, _p, _p, C.c_long, C.c_double, C.c_double, C.c_double, C.c_double, _i, _p],
     "flm_dqn_soft_update": [_p, _p, C.c_long, C.c_double, _p],

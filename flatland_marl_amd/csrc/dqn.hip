@@ -953,6 +953,134 @@ __global__ __launch_bounds__(1024) void head_backward_params_kernel(const float*
   }
 }
 
+// td_loss_kernel, head_backward_hidden_kernel, head_backward_params_kernel and the column sums of dhid
+// (colsum_kernel) in one launch, for a batch that one workgroup covers (B <= 1024) under double DQN: four dependent
+// launches of a few microseconds each are mostly launch latency.  Every workgroup works out the loss gradient of all
+// B samples itself (a few loads and a dozen operations per sample) and keeps it in LDS; workgroups 0..15 then own 64
+// hidden units each (dhid for every sample, summed over the samples in colsum_kernel's order: the first dense
+// layer's bias gradient), workgroups 16.. are head_backward_params_kernel's (64 hidden units, one output).  Every
+// sum keeps the order of the kernel it comes from; workgroup 0 also writes dq, the squared errors, their mean, dadv
+// and dval.
+__global__ __launch_bounds__(1024) void head_backward_fused_kernel(
+    const float* __restrict__ q, const float* __restrict__ q_next_local, const float* __restrict__ q_next_target,
+    const int64_t* __restrict__ action, const float* __restrict__ reward, const float* __restrict__ done, float gamma, int B,
+    int NA, const float* __restrict__ hid, const float* __restrict__ a2w, const float* __restrict__ v2w,
+    float* __restrict__ dq, float* __restrict__ sq_err, float* __restrict__ loss_out, float* __restrict__ dhid,
+    float* __restrict__ dadv, float* __restrict__ dval, float* __restrict__ g_a2w, float* __restrict__ g_a2b,
+    float* __restrict__ g_v2w, float* __restrict__ g_v2b, float* __restrict__ g_a1b, float* __restrict__ g_v1b,
+    float* __restrict__ sums_copy) {
+  __shared__ float s_da[FLM_DQN_MAX_ACTIONS][1024], s_dv[1024], s_sq[1024], s_red[16][64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const bool first = blockIdx.x == 0;
+  if (tid < B) {
+    const int b = tid;
+    int astar = 0;                                   // the first maximum
+    for (int a = 1; a < NA; a++)
+      if (q_next_local[b * NA + a] > q_next_local[b * NA + astar]) astar = a;
+    const float target = reward[b] + (gamma * q_next_target[b * NA + astar]) * (1.f - done[b]);
+    const int act = (int)min(max(action[b], (int64_t)0), (int64_t)(NA - 1));
+    const float diff = q[b * NA + act] - target;
+    s_sq[b] = diff * diff;
+    const float d_taken = 2.f * diff / (float)B;
+    // q = val + adv - mean(adv):  dval = sum_a dq[a],  dadv[a] = dq[a] - dval / NA
+    float da[FLM_DQN_MAX_ACTIONS], dv = 0.f;
+#pragma unroll
+    for (int a = 0; a < FLM_DQN_MAX_ACTIONS; a++) {
+      da[a] = a < NA && a == act ? d_taken : 0.f;
+      dv += da[a];
+    }
+    const float mean = NA == 2 ? 0.5f * dv : dv / (float)NA;
+#pragma unroll
+    for (int a = 0; a < FLM_DQN_MAX_ACTIONS; a++) {
+      if (first && a < NA) dq[b * NA + a] = da[a];
+      da[a] -= mean;
+      s_da[a][b] = da[a];
+      if (first && a < NA) dadv[b * NA + a] = da[a];
+    }
+    s_dv[b] = dv;
+    if (first) {
+      sq_err[b] = diff * diff;
+      dval[b] = dv;
+    }
+  }
+  __syncthreads();
+  if (first && tid < 64) {                           // the mean of the squared errors, in mean_kernel's order
+    float s = 0.f;
+    for (int i = tid; i < B; i += 64) s += s_sq[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (tid == 0) *loss_out = s / (float)B;
+  }
+  if (blockIdx.x < 16) {
+    // 64 hidden units: dhid of every sample, and its sum over the samples
+    const int n = blockIdx.x * 64 + lane;
+    const bool adv = blockIdx.x < 8;
+    const int i = adv ? n : n - 512;
+    float wcol[FLM_DQN_MAX_ACTIONS];
+#pragma unroll
+    for (int a = 0; a < FLM_DQN_MAX_ACTIONS; a++) wcol[a] = adv ? (a < NA ? a2w[a * 512 + i] : 0.f) : (a == 0 ? v2w[i] : 0.f);
+    auto row = [&](int m) -> float {
+      float g;
+      if (adv) {
+        g = s_da[0][m] * wcol[0];
+#pragma unroll
+        for (int a = 1; a < FLM_DQN_MAX_ACTIONS; a++)
+          if (a < NA) g = fmaf(s_da[a][m], wcol[a], g);
+      } else {
+        g = s_dv[m] * wcol[0];
+      }
+      const float out = hid[(long)m * 1024 + n] > 0.f ? g : 0.f;
+      dhid[(long)m * 1024 + n] = out;
+      return out;
+    };
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int m = w;
+    for (; m + 48 < B; m += 64) {
+      a0 += row(m);
+      a1 += row(m + 16);
+      a2 += row(m + 32);
+      a3 += row(m + 48);
+    }
+    for (; m < B; m += 16) a0 += row(m);
+    s_red[w][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (w == 0) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; k++) acc += s_red[k][lane];
+      if (adv) g_a1b[i] = acc;
+      else g_v1b[i] = acc;
+      if (sums_copy) sums_copy[n] = acc;
+    }
+  } else {
+    const int job = blockIdx.x - 16, bx = job & 7, a = job >> 3;
+    const int i = bx * 64 + lane;
+    const bool value = a == NA;
+    const float* d = value ? s_dv : s_da[a];
+    float acc = 0.f;
+    for (int b = w; b < B; b += 16) acc = fmaf(d[b], hid[(long)b * 1024 + (value ? 512 : 0) + i], acc);
+    s_red[w][lane] = acc;
+    __syncthreads();
+    if (w == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; k++) t += s_red[k][lane];
+      if (value) g_v2w[i] = t;
+      else g_a2w[a * 512 + i] = t;
+    }
+    if (bx == 0 && w == 1) {   // this output's bias gradient: one wave, lanes stride over the batch
+      float bsum = 0.f;
+      for (int b = lane; b < B; b += 64) bsum += d[b];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) bsum += __shfl_xor(bsum, o);
+      if (lane == 0) {
+        if (value) g_v2b[0] = bsum;
+        else g_a2b[a] = bsum;
+      }
+    }
+  }
+}
+
 // ---- optimiser and target network --------------------------------------------------------------------
 // torch.optim.Adam defaults (no weight decay, no amsgrad), one step over the flat buffers.  The products
 // are kept unfused so that every intermediate is rounded where the tensor-by-tensor formulation rounds it.
@@ -2106,31 +2234,35 @@ static int learn_dense_half(const float* local, const float* target, const float
                             stream);
   }
   if (rc) return rc;
-  bool mean_done = false;
   if (double_dqn && B <= 1024) {
-    hipLaunchKernelGGL(flm::td_loss_kernel, dim3(1), dim3(1024), 0, stream, w.q, w.qn, w.qt, action, reward, done, gamma, B,
-                       NA, w.dq, w.sq, loss_out);
-    mean_done = true;
-  } else if (double_dqn) {
-    hipLaunchKernelGGL(flm::td_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, w.q, w.qn, w.qt, action, reward, done,
-                       gamma, B, NA, w.dq, w.sq, (float*)nullptr);
+    // loss, head and the first dense layer's bias gradient (the column sums of dhid) in one launch
+    // (a copy of the sums in the workspace for the used-rails form: a data-parallel caller may be reducing grads by the
+    // time the second half reads them)
+    hipLaunchKernelGGL(flm::head_backward_fused_kernel, dim3(16 + 8 * (NA + 1)), dim3(1024), 0, stream, w.q, w.qn, w.qt, action,
+                       reward, done, gamma, B, NA, w.hid, local + L.a2_w, local + L.v2_w, w.dq, w.sq, loss_out, w.dhid, w.dadv,
+                       w.dval, grads + L.a2_w, grads + L.a2_b, grads + L.v2_w, grads + L.v2_b, grads + L.a1_b, grads + L.v1_b,
+                       R4 ? w.gsum : (float*)nullptr);
   } else {
-    hipLaunchKernelGGL(flm::td_loss_plain_kernel, dim3(1), dim3(1024), 0, stream, w.q, w.qt, action, reward, done, gamma, B,
-                       NA, w.dq, w.sq);
+    if (double_dqn) {
+      hipLaunchKernelGGL(flm::td_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, w.q, w.qn, w.qt, action, reward, done,
+                         gamma, B, NA, w.dq, w.sq, (float*)nullptr);
+    } else {
+      hipLaunchKernelGGL(flm::td_loss_plain_kernel, dim3(1), dim3(1024), 0, stream, w.q, w.qt, action, reward, done, gamma, B,
+                         NA, w.dq, w.sq);
+    }
+    hipLaunchKernelGGL(flm::mean_kernel, dim3(1), dim3(64), 0, stream, w.sq, B, loss_out);
+    // head
+    hipLaunchKernelGGL(flm::head_backward_hidden_kernel, dim3(B), dim3(64), 0, stream, w.hid, w.dq, local + L.a2_w,
+                       local + L.v2_w, B, NA, w.dhid, w.dadv, w.dval);
+    hipLaunchKernelGGL(flm::head_backward_params_kernel, dim3(8, NA + 1), dim3(1024), 0, stream, w.hid, w.dadv, w.dval, B, NA,
+                       grads + L.a2_w, grads + L.a2_b, grads + L.v2_w, grads + L.v2_b);
+    // the first dense layer's bias gradients = column sums of dhid
+    hipLaunchKernelGGL(flm::colsum_kernel, dim3(16), dim3(1024), 0, stream, w.dhid, B, 1024, 1024L, grads + L.a1_b, 512,
+                       grads + L.v1_b, R4 ? w.gsum : (float*)nullptr);
   }
-  if (!mean_done) hipLaunchKernelGGL(flm::mean_kernel, dim3(1), dim3(64), 0, stream, w.sq, B, loss_out);
-  // head
-  hipLaunchKernelGGL(flm::head_backward_hidden_kernel, dim3(B), dim3(64), 0, stream, w.hid, w.dq, local + L.a2_w,
-                     local + L.v2_w, B, NA, w.dhid, w.dadv, w.dval);
-  hipLaunchKernelGGL(flm::head_backward_params_kernel, dim3(8, NA + 1), dim3(1024), 0, stream, w.hid, w.dadv, w.dval, B, NA,
-                     grads + L.a2_w, grads + L.a2_b, grads + L.v2_w, grads + L.v2_b);
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   // first dense layer: weight gradients dW[n,j] = sum_b dhid[b,n] * x1[b,j], both streams as two groups of one launch
-  // (more workgroups per launch: fewer idle matrix pipes in the last round); bias gradients = column sums
-  // (a copy of the sums in the workspace for the used-rails form: a data-parallel caller may be reducing grads by the
-  // time the second half reads them)
-  hipLaunchKernelGGL(flm::colsum_kernel, dim3(16), dim3(1024), 0, stream, w.dhid, B, 1024, 1024L, grads + L.a1_b, 512,
-                     grads + L.v1_b, R4 ? w.gsum : (float*)nullptr);
+  // (more workgroups per launch: fewer idle matrix pipes in the last round)
   GemmArgs g{};
   g.A = w.dhid; g.B = w.x1; g.C = grads + L.a1_w;
   g.M = 512; g.N = (int)L.K1; g.K = B; g.lda = 1024; g.ldb = L.K1; g.ldc = L.K1;

@@ -34,10 +34,8 @@ __device__ __forceinline__ uint32_t replay_permute(uint32_t x, int hbits, uint32
   return (left << hbits) | right;
 }
 
-__global__ __launch_bounds__(256) void replay_sample_kernel(int size, int batch, uint32_t seed, uint32_t draw,
-                                                            int32_t* __restrict__ idx_out) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= batch) return;
+// entry j of the sample of (seed, draw) from 0 .. size-1
+__device__ __forceinline__ int32_t replay_sampled_index(int size, uint32_t seed, uint32_t draw, int j) {
   const int bits = size > 1 ? 32 - __clz(size - 1) : 1;
   const int hbits = (bits + 1) >> 1;                         // 2^(2*hbits) >= size, and < 4 * size
   const uint32_t k0 = replay_mix(seed ^ 0x27D4EB2Fu), k1 = replay_mix(draw * 0x9E3779B1u + seed);
@@ -45,7 +43,14 @@ __global__ __launch_bounds__(256) void replay_sample_kernel(int size, int batch,
   do {
     x = replay_permute(x, hbits, k0, k1);
   } while (x >= (uint32_t)size);                             // (ends: the walk returns to j < size at the latest)
-  idx_out[j] = (int32_t)x;
+  return (int32_t)x;
+}
+
+__global__ __launch_bounds__(256) void replay_sample_kernel(int size, int batch, uint32_t seed, uint32_t draw,
+                                                            int32_t* __restrict__ idx_out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= batch) return;
+  idx_out[j] = replay_sampled_index(size, seed, draw, j);
 }
 
 // One workgroup per (sampled transition, 16 KiB piece of a row): both observation rows with 16-byte copies;
@@ -95,6 +100,36 @@ __global__ __launch_bounds__(256) void replay_gather_planes_kernel(const uint8_t
     out_action[b] = action[idx[b]];
     out_reward[b] = reward[idx[b]];
     out_done[b] = done[idx[b]];
+  }
+}
+
+// flm_replay_sample and the gather in one launch: every workgroup works out the entry of its transition itself (the
+// same few dozen integer operations, on values that are the same for the whole workgroup), so the list of indices
+// never has to reach memory before the rows are fetched; it is still written, for callers that want it.
+// used_bytes == plane_bytes and n_planes * plane_bytes == row_bytes copies whole rows.
+__global__ __launch_bounds__(256) void replay_draw_gather_kernel(
+    const uint8_t* __restrict__ state, const uint8_t* __restrict__ next_state, const int64_t* __restrict__ action,
+    const float* __restrict__ reward, const float* __restrict__ done, int size, uint32_t seed, uint32_t draw, long row_bytes,
+    unsigned n_planes, unsigned plane_bytes, unsigned used_bytes, uint8_t* __restrict__ out_state,
+    uint8_t* __restrict__ out_next, int64_t* __restrict__ out_action, float* __restrict__ out_reward,
+    float* __restrict__ out_done, int32_t* __restrict__ idx_out) {
+  const int b = blockIdx.y;
+  const int32_t x = replay_sampled_index(size, seed, draw, b);
+  const long src = (long)x * row_bytes, dst = (long)b * row_bytes;
+  const unsigned total = used_bytes * n_planes;
+  const unsigned lo = blockIdx.x * 16384u;
+  const unsigned hi = lo + 16384u < total ? lo + 16384u : total;
+  for (unsigned o = lo + threadIdx.x * 16u; o < hi; o += 256u * 16u) {
+    const unsigned pl = o / used_bytes;
+    const long at = (long)pl * plane_bytes + (o - pl * used_bytes);
+    *reinterpret_cast<uint4*>(out_state + dst + at) = *reinterpret_cast<const uint4*>(state + src + at);
+    *reinterpret_cast<uint4*>(out_next + dst + at) = *reinterpret_cast<const uint4*>(next_state + src + at);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    out_action[b] = action[x];
+    out_reward[b] = reward[x];
+    out_done[b] = done[x];
+    idx_out[b] = x;
   }
 }
 
@@ -440,6 +475,27 @@ extern "C" int flm_replay_gather(const void* state, const void* next_state, cons
   hipLaunchKernelGGL(flm::replay_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)state,
                      (const uint8_t*)next_state, action, reward, done, idx, row_bytes, (uint8_t*)out_state, (uint8_t*)out_next,
                      out_action, out_reward, out_done);
+  FLM_CHECK_LAUNCH();
+  return FLM_OK;
+}
+
+extern "C" int flm_replay_draw_gather(const void* state, const void* next_state, const int64_t* action, const float* reward,
+                                      const float* done, int size, uint32_t seed, uint32_t draw, int batch, long row_bytes,
+                                      int n_planes, long plane_bytes, long used_bytes, void* out_state, void* out_next,
+                                      int64_t* out_action, float* out_reward, float* out_done, int32_t* idx, void* stream) {
+  if (!state || !next_state || !action || !reward || !done || !idx || !out_state || !out_next || !out_action || !out_reward ||
+      !out_done)
+    return FLM_E_ARG;
+  if (size <= 0 || batch <= 0 || batch > size || batch > 65535) return FLM_E_ARG;
+  if (row_bytes <= 0 || (row_bytes & 15) || n_planes <= 0 || plane_bytes <= 0 || (plane_bytes & 15) || used_bytes <= 0 ||
+      (used_bytes & 15) || used_bytes > plane_bytes || (long)n_planes * plane_bytes > row_bytes || row_bytes >= (1L << 31))
+    return FLM_E_ARG;
+  if (((uintptr_t)state | (uintptr_t)next_state | (uintptr_t)out_state | (uintptr_t)out_next) & 15) return FLM_E_ARG;
+  dim3 grid((unsigned)((used_bytes * n_planes + 16383) / 16384), (unsigned)batch);
+  hipLaunchKernelGGL(flm::replay_draw_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)state,
+                     (const uint8_t*)next_state, action, reward, done, size, seed, draw, row_bytes, (unsigned)n_planes,
+                     (unsigned)plane_bytes, (unsigned)used_bytes, (uint8_t*)out_state, (uint8_t*)out_next, out_action,
+                     out_reward, out_done, idx);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }

@@ -150,15 +150,13 @@ class DeviceReplay:
         if B > self.size:
             raise ValueError("Sample larger than population")
         st = torch.cuda.current_stream(self.device).cuda_stream
-        call("flm_replay_sample", self.size, B, self.seed, self.draws & 0xFFFFFFFF, ptr(idx), st)
-        self.draws += 1
+        # the draw and the gather are one launch
         used = (int(used_bytes) + 15) // 16 * 16
-        if used and len(self.row_shape) == 2 and self.dtype == torch.uint8 and used < self.row_shape[1] and \
-                self.row_shape[1] % 16 == 0:
-            call("flm_replay_gather_planes", ptr(self.state), ptr(self.next_state), ptr(self.action), ptr(self.reward),
-                 ptr(self.done), ptr(idx), B, self.row_bytes, self.row_shape[0], self.row_shape[1], used, ptr(s), ptr(sn),
-                 ptr(a), ptr(r), ptr(d), st)
-        else:
-            call("flm_replay_gather", ptr(self.state), ptr(self.next_state), ptr(self.action), ptr(self.reward),
-                 ptr(self.done), ptr(idx), B, self.row_bytes, ptr(s), ptr(sn), ptr(a), ptr(r), ptr(d), st)
+        planes = used and len(self.row_shape) == 2 and self.dtype == torch.uint8 and used < self.row_shape[1] and \
+            self.row_shape[1] % 16 == 0
+        shape = (self.row_shape[0], self.row_shape[1], used) if planes else (1, self.row_bytes, self.row_bytes)
+        call("flm_replay_draw_gather", ptr(self.state), ptr(self.next_state), ptr(self.action), ptr(self.reward),
+             ptr(self.done), self.size, self.seed, self.draws & 0xFFFFFFFF, B, self.row_bytes, *shape, ptr(s), ptr(sn),
+             ptr(a), ptr(r), ptr(d), ptr(idx), st)
+        self.draws += 1
         return s, a, r, sn, d

@@ -509,6 +509,14 @@ int flm_replay_gather_planes(const void* state, const void* next_state, const in
                              long plane_bytes, long used_bytes, void* out_state, void* out_next, int64_t* out_action,
                              float* out_reward, float* out_done, void* stream);
 
+/* flm_replay_sample(size, batch, seed, draw, idx) followed by flm_replay_gather_planes(..., idx, ...) in one launch:
+ * the same idx [batch] (still written) and the same gathered rows and scalars.  Whole rows: n_planes = 1,
+ * plane_bytes = used_bytes = row_bytes.  row_bytes < 2^31.  Replaces ReplayBuffer.sample, src/agent.py:159-174. */
+int flm_replay_draw_gather(const void* state, const void* next_state, const int64_t* action, const float* reward,
+                           const float* done, int size, uint32_t seed, uint32_t draw, int batch, long row_bytes,
+                           int n_planes, long plane_bytes, long used_bytes, void* out_state, void* out_next,
+                           int64_t* out_action, float* out_reward, float* out_done, int32_t* idx, void* stream);
+
 /* Storing one rollout step's transitions in the replay memory's ring.  Replaces the per-agent dqn.step(...) calls of
  * the training script's default feeding mode, src/main.py:275-278 (-> ReplayBuffer.add, src/agent.py:153-157), for
  * every environment of the batch at once.

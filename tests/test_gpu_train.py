@@ -452,6 +452,21 @@ def test_replay_sampling_kernel():
     assert torch.equal(s2[:, :, :32].cpu(), state[idx][:, :, :32]) and torch.equal(sn2[:, :, :32].cpu(), nxt[idx][:, :, :32])
     assert bool((s2[:, :, 32:] == 9).all()) and bool((sn2[:, :, 32:] == 9).all())
     assert torch.equal(ac2.cpu(), act[idx]) and torch.equal(rw2.cpu(), rew[idx]) and torch.equal(dn2.cpu(), done[idx])
+    assert torch.equal(rp._out[5].cpu().long(), idx)            # the one-launch form leaves the same list of entries
+    # the two-launch forms (flm_replay_sample, then flm_replay_gather / flm_replay_gather_planes): the same rows
+    from flatland_marl_amd._lib import call, ptr
+    di = idx.to(torch.int32).cuda()
+    o = [torch.full_like(rp._out[0], 9), torch.empty_like(ac), torch.empty_like(rw), torch.full_like(rp._out[3], 9), torch.empty_like(dn)]
+    call("flm_replay_gather", ptr(rp.state), ptr(rp.next_state), ptr(rp.action), ptr(rp.reward), ptr(rp.done), ptr(di), B,
+         rp.row_bytes, ptr(o[0]), ptr(o[3]), ptr(o[1]), ptr(o[2]), ptr(o[4]), 0)
+    torch.cuda.synchronize()
+    assert torch.equal(o[0].cpu(), state[idx]) and torch.equal(o[3].cpu(), nxt[idx]) and torch.equal(o[1], ac2)
+    assert torch.equal(o[2], rw2) and torch.equal(o[4], dn2)
+    o[0].fill_(9), o[3].fill_(9)
+    call("flm_replay_gather_planes", ptr(rp.state), ptr(rp.next_state), ptr(rp.action), ptr(rp.reward), ptr(rp.done),
+         ptr(di), B, rp.row_bytes, 3, 48, 32, ptr(o[0]), ptr(o[3]), ptr(o[1]), ptr(o[2]), ptr(o[4]), 0)
+    torch.cuda.synchronize()
+    assert torch.equal(o[0], s2) and torch.equal(o[3], sn2) and torch.equal(o[1], ac2)
     # the whole memory can be asked for; more than it holds cannot
     assert sorted(rp.sample_indices(n).cpu().tolist()) == list(range(n))
     with pytest.raises(ValueError):
