@@ -21,21 +21,51 @@ device = torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
 
 
 class FlatAdam:
-    """torch.optim.Adam (default betas/eps, no weight decay) over the network's flat parameter buffer."""
+    """torch.optim.Adam (default betas/eps, no weight decay) over the network's flat parameter buffer.
+
+    The moments m and v are flat buffers like the parameters.  While every step since they were zero has been a learn
+    step over the used rails, the moments of the first dense layer's weights under the empty rows are equal along the
+    rows; they are then kept once per (output unit, filter) in a small buffer and the large ones are left stale there
+    (flm_dqn_adam_soft_update_rails with moments_in / moments_out: a third less memory traffic, the same bits).
+    Reading .m or .v brings the large buffers up to date and ends that form for good: whoever holds them may write."""
 
     def __init__(self, network, lr, betas=(0.9, 0.999), eps=1e-8):
         self.network = network
         self.lr, self.betas, self.eps = lr, betas, eps
         self.step_count = 0
-        self.m = self.v = self.grads = None
+        self._m = self._v = self.grads = None
+        self._pairs = None                  # two buffers [2*512*64, 2] (m, v) under the empty rows; [0] is current
+        self._compact = None                # (Rp, T1, NA, rails4) while the large buffers are stale under rails >= rails4
+        self._uniform_from = 0              # moments known equal along the rows from this rail on (None: not known)
 
     def _ensure(self):
         flat = self.network.flat_params()
-        if self.m is None or self.m.device != flat.device:
-            self.m = torch.zeros_like(flat)
-            self.v = torch.zeros_like(flat)
+        if self._m is None or self._m.device != flat.device:
+            self._m = torch.zeros_like(flat)
+            self._v = torch.zeros_like(flat)
             self.grads = torch.zeros_like(flat)
+            self._compact, self._uniform_from, self._pairs = None, 0, None
         return flat
+
+    def _spread(self):
+        """The large moment buffers up to date again."""
+        if self._compact is not None:
+            Rp, T1, NA, rails4 = self._compact
+            call("flm_dqn_adam_moments", ptr(self._m), ptr(self._v), self._m.numel(), Rp, T1, NA, rails4, ptr(self._pairs[0]),
+                 1, torch.cuda.current_stream(self._m.device).cuda_stream)
+            self._compact = None
+
+    @property
+    def m(self):
+        self._spread()
+        self._uniform_from = None
+        return self._m
+
+    @property
+    def v(self):
+        self._spread()
+        self._uniform_from = None
+        return self._v
 
     def zero_grad(self):
         self._ensure()
@@ -49,18 +79,33 @@ class FlatAdam:
         flat = self._ensure()
         self.step_count += 1
         st = torch.cuda.current_stream(flat.device).cuda_stream
-        if target is None:
-            call("flm_dqn_adam", ptr(flat), ptr(self.grads), ptr(self.m), ptr(self.v), flat.numel(), float(self.lr),
-                 float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_count, st)
-        elif rails is not None:
+        hyper = (float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_count)
+        if target is not None and rails is not None:
             Rp, T1, NA, rails4, rcb = rails
-            call("flm_dqn_adam_soft_update_rails", ptr(flat), ptr(self.grads), ptr(self.m), ptr(self.v), ptr(target),
-                 flat.numel(), float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                 self.step_count, float(tau), int(Rp), int(T1), int(NA), int(rails4), ptr(rcb), st)
+            key = (int(Rp), int(T1), int(NA), int(rails4))
+            if self._compact is not None and self._compact != key:
+                self._spread()
+            if self._compact is None and self._uniform_from is not None and self._uniform_from <= rails4:
+                if self._pairs is None:
+                    self._pairs = [torch.empty((2 * 512 * 64, 2), dtype=torch.float32, device=flat.device) for _ in range(2)]
+                call("flm_dqn_adam_moments", ptr(self._m), ptr(self._v), flat.numel(), *key, ptr(self._pairs[0]), 0, st)
+                self._compact = key
+            if self._uniform_from is not None:
+                self._uniform_from = max(self._uniform_from, int(rails4))
+            pairs = (ptr(self._pairs[0]), ptr(self._pairs[1])) if self._compact is not None else (None, None)
+            call("flm_dqn_adam_soft_update_rails", ptr(flat), ptr(self.grads), ptr(self._m), ptr(self._v), ptr(target),
+                 flat.numel(), *hyper, float(tau), *key, ptr(rcb), *pairs, st)
+            if self._compact is not None:
+                self._pairs.reverse()
+            return
+        # any other step gives the weights under the empty rows gradients of their own
+        self._spread()
+        self._uniform_from = None
+        if target is None:
+            call("flm_dqn_adam", ptr(flat), ptr(self.grads), ptr(self._m), ptr(self._v), flat.numel(), *hyper, st)
         else:
-            call("flm_dqn_adam_soft_update", ptr(flat), ptr(self.grads), ptr(self.m), ptr(self.v), ptr(target),
-                 flat.numel(), float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                 self.step_count, float(tau), st)
+            call("flm_dqn_adam_soft_update", ptr(flat), ptr(self.grads), ptr(self._m), ptr(self._v), ptr(target),
+                 flat.numel(), *hyper, float(tau), st)
 
 
 class DQNAgent:

@@ -1139,11 +1139,18 @@ __device__ __forceinline__ unsigned div_small(unsigned n, unsigned d, float inv_
   else if ((q + 1) * d <= n) q++;
   return q;
 }
+// COMPACT: the two moments of the weights under the empty rows are kept once per (output unit, filter) instead of
+// once per weight.  Those weights have received the same gradient in every step so far (the caller's condition), so
+// their moments are the same along the rows: mv_in [2][512][64] pairs (m, v) holds them, the pass reads them from
+// there, leaves m and v under the empty rows alone and writes the new pair to mv_out (another buffer: other threads are
+// still reading mv_in).  The parameters and the target are updated element by element as before: the same bits.
+template <bool COMPACT>
 __global__ __launch_bounds__(256) void adam_soft_update_rails_kernel(
     float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
     float* __restrict__ target, long n, float one_minus_b1, float beta2, float one_minus_b2, float eps, float step_size,
     float bc2_sqrt, float tau, float one_minus_tau, long a1_w, long a1_b, long v1_w, long v1_b, unsigned K1, unsigned H3,
-    unsigned Rp, unsigned R4, float inv_K1, float inv_H3, float inv_Rp, const float* __restrict__ rcb) {
+    unsigned Rp, unsigned R4, float inv_K1, float inv_H3, float inv_Rp, const float* __restrict__ rcb,
+    const float2* __restrict__ mv_in, float2* __restrict__ mv_out) {
   // four consecutive parameters per thread (the two weight blocks start and end on multiples of four, so a thread's
   // four lie inside one or outside both): their place (output unit, filter, rail) is worked out once and stepped
   const long i0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -1163,11 +1170,14 @@ __global__ __launch_bounds__(256) void adam_soft_update_rails_kernel(
   const float* gb = g + (adv ? a1_b : v1_b);
   const bool whole = i0 + 3 < n;
   float pv[4], mv[4], vv[4], tv[4], gv[4];
-  bool synth[4];
+  bool synth[4], owner[4];
+  unsigned pair[4];
 #pragma unroll
   for (int e = 0; e < 4; e++) {
     synth[e] = (adv || val) && rail >= R4;
     gv[e] = synth[e] ? rcb[c] * gb[o] : 0.f;
+    pair[e] = ((adv ? 0u : 512u) + o) * 64u + c;
+    owner[e] = synth[e] && pl == 0 && rail == R4;
     if (++rail == Rp) {
       rail = 0;
       if (++pl == 3) {
@@ -1176,14 +1186,18 @@ __global__ __launch_bounds__(256) void adam_soft_update_rails_kernel(
       }
     }
   }
+  const bool all_synth = synth[0] && synth[1] && synth[2] && synth[3];
+  const bool moments = !(COMPACT && all_synth);            // this thread reads and writes m and v
   if (whole) {
-    const float4 p4 = *reinterpret_cast<const float4*>(p + i0), m4 = *reinterpret_cast<const float4*>(m + i0);
-    const float4 v4 = *reinterpret_cast<const float4*>(v + i0), t4 = *reinterpret_cast<const float4*>(target + i0);
+    const float4 p4 = *reinterpret_cast<const float4*>(p + i0), t4 = *reinterpret_cast<const float4*>(target + i0);
     pv[0] = p4.x; pv[1] = p4.y; pv[2] = p4.z; pv[3] = p4.w;
-    mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
-    vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
     tv[0] = t4.x; tv[1] = t4.y; tv[2] = t4.z; tv[3] = t4.w;
-    if (!(synth[0] && synth[1] && synth[2] && synth[3])) {
+    if (moments) {
+      const float4 m4 = *reinterpret_cast<const float4*>(m + i0), v4 = *reinterpret_cast<const float4*>(v + i0);
+      mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
+      vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
+    }
+    if (!all_synth) {
       const float4 g4 = *reinterpret_cast<const float4*>(g + i0);
       if (!synth[0]) gv[0] = g4.x;
       if (!synth[1]) gv[1] = g4.y;
@@ -1200,20 +1214,64 @@ __global__ __launch_bounds__(256) void adam_soft_update_rails_kernel(
         pv[e] = mv[e] = vv[e] = tv[e] = gv[e] = 0.f;
       }
   }
+  if (COMPACT) {
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+      if (synth[e]) {
+        const float2 mvp = mv_in[pair[e]];
+        mv[e] = mvp.x;
+        vv[e] = mvp.y;
+      }
+  }
 #pragma unroll
   for (int e = 0; e < 4; e++) {
     adam_element(pv[e], gv[e], mv[e], vv[e], k);
     tv[e] = soft_element(pv[e], tv[e], k);
   }
+  if (COMPACT) {
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+      if (owner[e]) mv_out[pair[e]] = make_float2(mv[e], vv[e]);
+  }
   if (whole) {
     *reinterpret_cast<float4*>(p + i0) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-    *reinterpret_cast<float4*>(m + i0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
-    *reinterpret_cast<float4*>(v + i0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
     *reinterpret_cast<float4*>(target + i0) = make_float4(tv[0], tv[1], tv[2], tv[3]);
+    if (moments) {
+      *reinterpret_cast<float4*>(m + i0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+      *reinterpret_cast<float4*>(v + i0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    }
   } else {
 #pragma unroll
     for (int e = 0; e < 4; e++)
       if (i0 + e < n) { p[i0 + e] = pv[e]; m[i0 + e] = mv[e]; v[i0 + e] = vv[e]; target[i0 + e] = tv[e]; }
+  }
+}
+
+// The moments under the empty rows, between their two forms.  take: pair[(stream, o, c)] = (m, v) of that unit and
+// filter at plane 0, rail R4 (one of the equal ones).  fill: every m and v under the empty rows from its pair.
+__global__ __launch_bounds__(256) void adam_moments_take_kernel(const float* __restrict__ m, const float* __restrict__ v,
+                                                                long a1_w, long v1_w, long K1, int H3, int R4,
+                                                                float2* __restrict__ pairs) {
+  const int i = blockIdx.x * 256 + threadIdx.x;               // (stream*512 + o)*64 + c
+  if (i >= 2 * 512 * 64) return;
+  const int c = i & 63, o = (i >> 6) & 511;
+  const long at = (i >= 512 * 64 ? v1_w : a1_w) + (long)o * K1 + (long)c * H3 + R4;
+  pairs[i] = make_float2(m[at], v[at]);
+}
+__global__ __launch_bounds__(256) void adam_moments_fill_kernel(float* __restrict__ m, float* __restrict__ v, long a1_w, long v1_w,
+                                                                long K1, int H3, int Rp, int R4,
+                                                                const float2* __restrict__ pairs) {
+  const int o = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;      // o: stream*512 + unit
+  const long base = (o < 512 ? a1_w + (long)o * K1 : v1_w + (long)(o - 512) * K1);
+  const int L = Rp - R4;
+  for (int sg = w; sg < 192; sg += 4) {
+    const int c = sg / 3, pl = sg - 3 * c;
+    const float2 mvp = pairs[o * 64 + c];
+    const long at = base + (long)c * H3 + (long)pl * Rp + R4;
+    for (int i = lane; i < L; i += 64) {
+      m[at + i] = mvp.x;
+      v[at + i] = mvp.y;
+    }
   }
 }
 
@@ -2482,19 +2540,43 @@ extern "C" long flm_dqn_learn_rails_rcb_offset(int B, int Rp, int T1, int NA) {
 
 extern "C" int flm_dqn_adam_soft_update_rails(float* params, const float* grads, float* m, float* v, float* target, long n,
                                               double lr, double beta1, double beta2, double eps, int step, double tau, int Rp,
-                                              int T1, int NA, int rails4, const float* rcb, void* stream) {
+                                              int T1, int NA, int rails4, const float* rcb, const float* moments_in,
+                                              float* moments_out, void* stream) {
   if (!params || !grads || !m || !v || !target || !rcb || n <= 0 || step <= 0 || Rp <= 0 || T1 <= 0 || !actions_ok(NA))
     return FLM_E_ARG;
   const DqnLayout L(3 * Rp, T1, NA);
   if (n != L.total || rails4 <= 0 || rails4 >= Rp || (rails4 & 3) || 512L * L.K1 >= (1L << 24)) return FLM_E_ARG;
   if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v | (uintptr_t)target) & 15) return FLM_E_ARG;
+  if (!moments_in != !moments_out || (moments_in && moments_in == moments_out) ||
+      (((uintptr_t)moments_in | (uintptr_t)moments_out) & 7))
+    return FLM_E_ARG;
   const double bc1 = 1.0 - pow(beta1, (double)step);
   const double bc2 = 1.0 - pow(beta2, (double)step);
-  hipLaunchKernelGGL(flm::adam_soft_update_rails_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream,
-                     params, grads, m, v, target, n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
-                     (float)(lr / bc1), (float)sqrt(bc2), (float)tau, (float)(1.0 - tau), L.a1_w, L.a1_b, L.v1_w, L.v1_b,
-                     (unsigned)L.K1, (unsigned)(3 * Rp), (unsigned)Rp, (unsigned)rails4, 1.0f / (float)L.K1,
-                     1.0f / (float)(3 * Rp), 1.0f / (float)Rp, rcb);
+  const dim3 grid((unsigned)((n + 1023) / 1024));
+#define FLM_ADAM_RAILS(COMPACT)                                                                                              \
+  hipLaunchKernelGGL(flm::adam_soft_update_rails_kernel<COMPACT>, grid, dim3(256), 0, (hipStream_t)stream, params, grads, m, v,  \
+                     target, n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)(lr / bc1),       \
+                     (float)sqrt(bc2), (float)tau, (float)(1.0 - tau), L.a1_w, L.a1_b, L.v1_w, L.v1_b, (unsigned)L.K1,         \
+                     (unsigned)(3 * Rp), (unsigned)Rp, (unsigned)rails4, 1.0f / (float)L.K1, 1.0f / (float)(3 * Rp),           \
+                     1.0f / (float)Rp, rcb, reinterpret_cast<const float2*>(moments_in), reinterpret_cast<float2*>(moments_out))
+  if (moments_in) FLM_ADAM_RAILS(true);
+  else FLM_ADAM_RAILS(false);
+#undef FLM_ADAM_RAILS
+  if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
+  return FLM_OK;
+}
+
+extern "C" int flm_dqn_adam_moments(float* m, float* v, long n, int Rp, int T1, int NA, int rails4, float* moments, int fill,
+                                    void* stream) {
+  if (!m || !v || !moments || n <= 0 || Rp <= 0 || T1 <= 0 || !actions_ok(NA) || ((uintptr_t)moments & 7)) return FLM_E_ARG;
+  const DqnLayout L(3 * Rp, T1, NA);
+  if (n != L.total || rails4 <= 0 || rails4 >= Rp) return FLM_E_ARG;
+  if (fill)
+    hipLaunchKernelGGL(flm::adam_moments_fill_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, m, v, L.a1_w, L.v1_w, L.K1,
+                       3 * Rp, Rp, rails4, reinterpret_cast<const float2*>(moments));
+  else
+    hipLaunchKernelGGL(flm::adam_moments_take_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, m, v, L.a1_w, L.v1_w, L.K1,
+                       3 * Rp, rails4, reinterpret_cast<float2*>(moments));
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
 }

@@ -794,7 +794,7 @@ def test_learn_over_the_used_rails_matches_the_plain_learn_step(Rp, T1, B, rails
             if fused:
                 off = query("flm_dqn_learn_rails_rcb_offset", B, Rp, T1, 2)
                 call("flm_dqn_adam_soft_update_rails", ptr(p_), ptr(gbuf), ptr(m_), ptr(v_), ptr(t_), n, 1e-3, 0.9, 0.999, 1e-8, 3,
-                     0.01, Rp, T1, 2, rails4, ptr(ws[off:off + 64]), st)
+                     0.01, Rp, T1, 2, rails4, ptr(ws[off:off + 64]), None, None, st)
             else:
                 assert not torch.isnan(gbuf).any()
                 call("flm_dqn_adam_soft_update", ptr(p_), ptr(gbuf), ptr(m_), ptr(v_), ptr(t_), n, 1e-3, 0.9, 0.999, 1e-8, 3, 0.01, st)
@@ -803,3 +803,90 @@ def test_learn_over_the_used_rails_matches_the_plain_learn_step(Rp, T1, B, rails
         for x, y in zip(*outs):
             assert torch.equal(x, y)
         assert not torch.equal(outs[0][0], local)
+
+
+def test_optimizer_with_the_moments_under_the_empty_rows_kept_once_gives_the_same_bits():
+    """FlatAdam keeps the moments of the first dense layer's weights under the empty rows once per (unit, filter) while
+    every step ran over the used rails: parameters and target after several steps (the used rails growing on the way),
+    and the moments once they are read, equal those of the pass that keeps every moment."""
+    from flatland_marl_amd._lib import call, ptr, query
+    from flatland_marl_amd.agent import FlatAdam
+    from flatland_marl_amd.model import Dueling_DQN
+    Rp, T1, NA = 70, 151, 2
+    torch.manual_seed(5)
+    net = Dueling_DQN(T1, 3 * Rp, NA).to("cuda")
+    flat = net.flat_params()
+    n = flat.numel()
+    assert n == query("flm_dqn_param_count", 3 * Rp, T1, NA)
+    K1 = 64 * 3 * Rp
+    a1_w = 64 * T1 + 64
+    v1_w = a1_w + 512 * K1 + 512
+    opt = FlatAdam(net, lr=1e-3)
+    opt._ensure()
+    p_e, t_e = flat.clone(), torch.randn(n, generator=torch.Generator().manual_seed(6)).cuda()
+    t_c = t_e.clone()
+    m_e, v_e = torch.zeros_like(flat), torch.zeros_like(flat)
+    gen = torch.Generator().manual_seed(7)
+    forms = []
+    for step, r4 in enumerate((20, 20, 24, 24, 24, 32), 1):
+        g = torch.randn(n, generator=gen).cuda() * 0.1
+        for w in (a1_w, v1_w):                                   # what a learn step with fill_padding = 0 leaves unwritten
+            g[w:w + 512 * K1].view(512, 64, 3, Rp)[:, :, :, r4:] = float("nan")
+        rcb = torch.rand(64, generator=gen).cuda()
+        rcb[::5] = 0.0
+        call("flm_dqn_adam_soft_update_rails", ptr(p_e), ptr(g), ptr(m_e), ptr(v_e), ptr(t_e), n, 1e-3, 0.9, 0.999, 1e-8, step,
+             0.01, Rp, T1, NA, r4, ptr(rcb), None, None, 0)
+        opt.grads.copy_(g)
+        opt.step(target=t_c, tau=0.01, rails=(Rp, T1, NA, r4, rcb))
+        forms.append(opt._compact)
+        torch.cuda.synchronize()
+        assert torch.equal(flat, p_e) and torch.equal(t_c, t_e), step
+    assert forms == [(Rp, T1, NA, 20)] * 2 + [(Rp, T1, NA, 24)] * 3 + [(Rp, T1, NA, 32)]
+    stale = not torch.equal(opt._m, m_e)
+    assert stale                                                  # the large buffers were indeed left behind
+    assert torch.equal(opt.m, m_e) and torch.equal(opt.v, v_e)    # reading them brings them up to date
+    assert opt._compact is None and opt._uniform_from is None
+    assert not torch.isnan(m_e).any() and not torch.isnan(p_e).any()
+    # ... and from then on every moment is kept: one more step over the used rails, then a plain one
+    g = torch.randn(n, generator=gen).cuda() * 0.1
+    rcb = torch.rand(64, generator=gen).cuda()
+    call("flm_dqn_adam_soft_update_rails", ptr(p_e), ptr(g), ptr(m_e), ptr(v_e), ptr(t_e), n, 1e-3, 0.9, 0.999, 1e-8, 7, 0.01,
+         Rp, T1, NA, 32, ptr(rcb), None, None, 0)
+    opt.grads.copy_(g)
+    opt.step(target=t_c, tau=0.01, rails=(Rp, T1, NA, 32, rcb))
+    assert opt._compact is None
+    call("flm_dqn_adam_soft_update", ptr(p_e), ptr(g), ptr(m_e), ptr(v_e), ptr(t_e), n, 1e-3, 0.9, 0.999, 1e-8, 8, 0.01, 0)
+    opt.step(target=t_c, tau=0.01)
+    torch.cuda.synchronize()
+    assert torch.equal(flat, p_e) and torch.equal(t_c, t_e) and torch.equal(opt._m, m_e) and torch.equal(opt._v, v_e)
+
+
+def test_a_plain_step_after_steps_over_the_used_rails_finds_every_moment():
+    """A step that is not over the used rails (here: the float learn path's) first spreads the moments kept once."""
+    from flatland_marl_amd._lib import call, ptr
+    from flatland_marl_amd.agent import FlatAdam
+    from flatland_marl_amd.model import Dueling_DQN
+    Rp, T1, NA = 40, 31, 2
+    torch.manual_seed(8)
+    net = Dueling_DQN(T1, 3 * Rp, NA).to("cuda")
+    flat = net.flat_params()
+    n = flat.numel()
+    opt = FlatAdam(net, lr=1e-3)
+    opt._ensure()
+    p_e, t_e = flat.clone(), torch.zeros_like(flat)
+    t_c, m_e, v_e = t_e.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
+    gen = torch.Generator().manual_seed(9)
+    for step in (1, 2, 3):
+        g = torch.randn(n, generator=gen).cuda()
+        rcb = torch.rand(64, generator=gen).cuda()
+        if step < 3:
+            call("flm_dqn_adam_soft_update_rails", ptr(p_e), ptr(g), ptr(m_e), ptr(v_e), ptr(t_e), n, 1e-3, 0.9, 0.999, 1e-8,
+                 step, 0.01, Rp, T1, NA, 12, ptr(rcb), None, None, 0)
+        else:
+            call("flm_dqn_adam_soft_update", ptr(p_e), ptr(g), ptr(m_e), ptr(v_e), ptr(t_e), n, 1e-3, 0.9, 0.999, 1e-8, step,
+                 0.01, 0)
+        opt.grads.copy_(g)
+        opt.step(target=t_c, tau=0.01, rails=(Rp, T1, NA, 12, rcb) if step < 3 else None)
+        assert (opt._compact is not None) == (step < 3)
+    torch.cuda.synchronize()
+    assert torch.equal(flat, p_e) and torch.equal(t_c, t_e) and torch.equal(opt._m, m_e) and torch.equal(opt._v, v_e)
