@@ -68,14 +68,19 @@ class Dueling_DQN(nn.Module):
         ask for a different B every step, and handing a buffer of a new size back and forth to the caching
         allocator costs device allocations in the middle of the step."""
         dev = self._flat.device
-        need = query("flm_dqn_forward_workspace", B, self.height)
         ws = self._ws.get("buf")
+        if ws is not None and ws.device == dev and B <= self._ws["rows"]:
+            return ws
+        need = query("flm_dqn_forward_workspace", B, self.height)
         if ws is None or ws.device != dev or ws.numel() < need:
             self._ws = {}
             ws = None                                           # release the old buffer before taking a larger one
-            grow = query("flm_dqn_forward_workspace", B + B // 4 + 1, self.height)
-            self._ws = {"buf": torch.empty(grow, dtype=torch.float32, device=dev)}
+            rows = B + B // 4 + 1
+            grow = query("flm_dqn_forward_workspace", rows, self.height)
+            self._ws = {"buf": torch.empty(grow, dtype=torch.float32, device=dev), "rows": rows}
             ws = self._ws["buf"]
+        else:
+            self._ws["rows"] = max(self._ws["rows"], B)
         return ws
 
     def forward(self, x):
@@ -89,17 +94,20 @@ class Dueling_DQN(nn.Module):
              torch.cuda.current_stream(flat.device).cuda_stream)
         return q
 
-    def forward_obs(self, obs_u8, plane_stride, rails_used=0):
+    def forward_obs(self, obs_u8, plane_stride, rails_used=0, out=None, flat=None):
         """Q-values [n,action_space] straight from uint8 observations [n,3,plane_stride] (plane 0 int8, heat planes uint8,
         rows of `width` bytes): the convolution reads the bytes, no float copy of the input is made.
         rails_used > 0: the caller vouches that rails rails_used.. of every plane are empty (the padding up to
-        max_rails); they are then not computed but enter through the first dense layer's bias."""
-        flat = self.flat_params()
+        max_rails); they are then not computed but enter through the first dense layer's bias.
+        out: a float32 buffer of at least n rows for the result; flat: what flat_params() returned a moment ago (a
+        caller in a hurry asks for it ahead of time)."""
+        if flat is None:
+            flat = self.flat_params()
         if self.height % 3:
             raise ValueError("observations have three planes: the network height must be 3*max_rails")
         obs_u8 = obs_u8.contiguous()
         n = obs_u8.size(0)
-        q = torch.empty((n, self.action_space), dtype=torch.float32, device=flat.device)
+        q = torch.empty((n, self.action_space), dtype=torch.float32, device=flat.device) if out is None else out[:n]
         call("flm_dqn_forward_u8_rails", ptr(flat), ptr(obs_u8), n, self.height // 3, self.width, int(plane_stride),
              self.action_space, int(rails_used), ptr(self._workspace(n)), ptr(q),
              torch.cuda.current_stream(flat.device).cuda_stream)

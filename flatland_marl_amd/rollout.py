@@ -79,6 +79,7 @@ class RolloutBatch:
         self.cols = None
         self._agent_flat = None
         self._alt_pool = None
+        self._rails_used = None             # (of the batch's graphs: asked for again after a reset)
         self.t = 0
         self.malfunction = self.malfunction_moving = self.env_seed = None
         self.malf_threshold, self.malf_min, self.malf_max = 0, 0, 0
@@ -128,6 +129,7 @@ class RolloutBatch:
         if getattr(b, "dist", None) is None:
             b.compute_distances()
         b.shortest_paths()
+        self._rails_used = None
         self.cols = b.columns(shift=1)
         n = min(b.Lcap, self.Lp)
         self.path_cell[:, :, :n] = b.path_cell[:, :, :n]
@@ -146,43 +148,55 @@ class RolloutBatch:
              self.Lp, ptr(self.branch), ptr(self.before_switch), self.stream)
         return self.branch
 
-    def alternatives(self, req, ready=None):
+    def _alt_tables(self):
+        """Pointers of the tables flm_altpaths reads: gathered before the host waits for the step's sizes, so that the
+        launch follows the wait at once."""
+        b = self.b
+        return (ptr(b.grid), ptr(b.cell_idx), ptr(b.dist), ptr(b.succ_table()), ptr(b.choice_table()), ptr(b.idx_cell),
+                ptr(b.tslot), ptr(b.node_id)), (ptr(b.pos_cell), ptr(b.direction), ptr(b.target_cell))
+
+    def _alt_pool_for(self, n, n_ready):
+        # the tables live in buffers that only ever grow: a step allocates nothing once they have reached the
+        # largest number of agents in front of a switch seen so far
+        b, K, pool = self.b, self.cap_alt, self._alt_pool
+        if pool is None or pool["cap"] < n or pool["cap_rows"] < n_ready + n * K:
+            i32 = dict(dtype=torch.int32, device=self.device)
+            cap = max(n, 64, 0 if pool is None else pool["cap"] * 3 // 2)
+            cap_rows = max(n_ready + n * K, self.E * self.A + cap * K)
+            pool = self._alt_pool = dict(
+                cap=cap, cap_rows=cap_rows, count=torch.empty((cap,), **i32), len=torch.zeros((cap, K), **i32),
+                cell=torch.empty((cap, K, self.Lp), **i32), meta=torch.empty((cap, K, self.Lp), **i32),
+                err=torch.empty((cap,), **i32), cols=torch.empty((cap, K, b.T1), dtype=torch.int16, device=self.device),
+                col_err=torch.empty((cap, K), **i32), row_offset=torch.empty((cap + 1,), **i32),
+                row_req=torch.empty((cap_rows,), **i32), row_own=torch.empty((cap_rows,), **i32))
+            pool["base"] = tuple(pool[k].data_ptr() for k in ("count", "len", "cell", "meta", "err"))
+        return pool
+
+    def alternatives(self, req, ready=None, tables=None):
         """Alternative paths and their planes (column form) for the agents req[n] (flat e*A+a, all ACTIVE):
         get_altmaps, src/rail_observations.py:97-111.  The batch's pos_cell / direction / status must hold
         the agents' current state (step() sees to it).  ready: the departing agents of the same step; the
         rows the network has to evaluate (ready first, then every alternative) are listed in row_req /
         row_own, their number in req_counts[2]."""
         b = self.b
-        n, K, dev = req.numel(), self.cap_alt, self.device
-        i32 = dict(dtype=torch.int32, device=dev)
+        n, K = req.numel(), self.cap_alt
         n_ready = 0 if ready is None else ready.numel()
-        # the tables live in buffers that only ever grow: a step allocates nothing once they have reached the
-        # largest number of agents in front of a switch seen so far
-        pool = self._alt_pool
-        if pool is None or pool["cap"] < n or pool["cap_rows"] < n_ready + n * K:
-            cap = max(n, 64, 0 if pool is None else pool["cap"] * 3 // 2)
-            cap_rows = max(n_ready + n * K, self.E * self.A + cap * K)
-            pool = self._alt_pool = dict(
-                cap=cap, cap_rows=cap_rows, count=torch.empty((cap,), **i32), len=torch.zeros((cap, K), **i32),
-                cell=torch.empty((cap, K, self.Lp), **i32), meta=torch.empty((cap, K, self.Lp), **i32),
-                err=torch.empty((cap,), **i32), cols=torch.empty((cap, K, b.T1), dtype=torch.int16, device=dev),
-                col_err=torch.empty((cap, K), **i32), row_offset=torch.empty((cap + 1,), **i32),
-                row_req=torch.empty((cap_rows,), **i32), row_own=torch.empty((cap_rows,), **i32))
+        pool = self._alt_pool_for(n, n_ready)
+        fixed, state = tables if tables is not None else self._alt_tables()
+        p_count, p_len, p_cell, p_meta, p_err = pool["base"]
+        p_req, st, Lp = ptr(req), self.stream, self.Lp
+        for lo in range(0, n, MAX_REQ):
+            call("flm_altpaths", *fixed, p_req + 4 * lo, min(n, lo + MAX_REQ) - lo, *state, self.E, self.A, b.H, b.W, b.cap_cells,
+                 self.max_alt_depth, K, Lp, p_count + 4 * lo, p_len + 4 * K * lo, p_cell + 4 * K * Lp * lo,
+                 p_meta + 4 * K * Lp * lo, p_err + 4 * lo, st)
+        # (the views below are made while the device follows the paths)
         alt = dict(count=pool["count"][:n], len=pool["len"][:n], cell=pool["cell"][:n], meta=pool["meta"][:n],
                    err=pool["err"][:n], cols=pool["cols"][:n], col_err=pool["col_err"][:n], req=req,
                    row_offset=pool["row_offset"][:n + 1], row_req=pool["row_req"][:n_ready + n * K],
                    row_own=pool["row_own"][:n_ready + n * K])
-        for lo in range(0, n, MAX_REQ):
-            hi = min(n, lo + MAX_REQ)
-            call("flm_altpaths", ptr(b.grid), ptr(b.cell_idx), ptr(b.dist), ptr(b.succ_table()), ptr(b.choice_table()),
-                 ptr(b.idx_cell), ptr(b.tslot), ptr(b.node_id),
-                 ptr(req[lo:hi]),
-                 hi - lo, ptr(b.pos_cell), ptr(b.direction), ptr(b.target_cell), self.E, self.A, b.H, b.W, b.cap_cells,
-                 self.max_alt_depth, K, self.Lp, ptr(alt["count"][lo:hi]), ptr(alt["len"][lo:hi]), ptr(alt["cell"][lo:hi]),
-                 ptr(alt["meta"][lo:hi]), ptr(alt["err"][lo:hi]), self.stream)
         # one path per (request, alternative); unused alternatives have length 0
         if self._agent_flat is None or self._agent_flat.numel() < n * K:
-            self._agent_flat = torch.empty((max(n * K, 1024),), **i32)
+            self._agent_flat = torch.empty((max(n * K, 1024),), dtype=torch.int32, device=self.device)
         agent_flat = self._agent_flat[:n * K]
         agent_flat.view(n, K).copy_(req[:, None].expand(n, K))
         call("flm_columns", ptr(alt["cell"]), ptr(alt["len"]), ptr(agent_flat), ptr(b.pos_cell), ptr(b.target_cell),
@@ -203,14 +217,15 @@ class RolloutBatch:
         n = req.numel()
         if out is None:
             out = torch.empty((n, 3, b.plane_stride), dtype=torch.uint8, device=self.device)
+        p_req, p_out, p_cols = ptr(req), ptr(out), ptr(own_cols) if own_cols is not None else None
+        p_row = ptr(own_row) if own_row is not None else None
         for lo in range(0, n, MAX_REQ):
-            hi = min(n, lo + MAX_REQ)
-            if own_row is not None:
-                oc, orow = ptr(own_cols), ptr(own_row[lo:hi])
+            if p_row is not None:
+                oc, orow = p_cols, p_row + 4 * lo
             else:
-                oc, orow = (ptr(own_cols[lo:hi]) if own_cols is not None else None), None
-            call("flm_observations_req_columns", ptr(self.cols), ptr(req[lo:hi]), oc, orow, hi - lo, self.E, self.A,
-                 b.Rp, b.T1, b.plane_stride, ptr(out[lo:hi]), self.stream)
+                oc, orow = (p_cols + 2 * b.T1 * lo if p_cols is not None else None), None
+            call("flm_observations_req_columns", ptr(self.cols), p_req + 4 * lo, oc, orow, min(n, lo + MAX_REQ) - lo, self.E,
+                 self.A, b.Rp, b.T1, b.plane_stride, p_out + 3 * b.plane_stride * lo, self.stream)
         return out
 
     def apply(self, net_in, best, alt):
@@ -254,9 +269,14 @@ class RolloutBatch:
              ptr(b.start_cell), self.E, self.A, ptr(self.ready_list), ptr(self.switch_list), ptr(self.req_counts),
              ptr(self.alt_slot), ptr(self._net), ptr(self._best), ptr(b.pos_cell), ptr(b.direction), ptr(b.status),
              ptr(self._req_ws), self.stream)
+        # what needs no sizes is done before the host waits for them: the device is still busy with the kernels above
+        tables = self._alt_tables()
+        prepare = getattr(policy, "prepare", None)
+        if prepare is not None:
+            prepare(self)
         n_ready, n_switch = self.read_counts()[:2]             # the host waits for the step's sizes
         req_ready, req_switch = self.ready_list[:n_ready], self.switch_list[:n_switch]
-        alt = self.alternatives(req_switch, req_ready) if n_switch else None
+        alt = self.alternatives(req_switch, req_ready, tables) if n_switch else None
         info = dict(t=self.t, branch=self.branch, req_ready=req_ready, req_switch=req_switch, alt=alt,
                     net=self._net, best=self._best)
         net_in, best = policy(self, info)
@@ -269,7 +289,9 @@ class RolloutBatch:
     def rails_used(self):
         """The largest number of rails of any environment of the batch: rows from there on are empty in every plane
         of every observation (the padding up to max_rails)."""
-        return int(np.asarray(self.b.R).max())
+        if self._rails_used is None:
+            self._rails_used = int(np.asarray(self.b.R).max())
+        return self._rails_used
 
     def read_counts(self):
         """[departing agents, agents before a switch, network rows] as the kernels enqueued so far leave them."""

@@ -43,7 +43,8 @@ class DQNPolicy:
     """policy(rollout, info) for RolloutBatch.step: one forward pass over the observations of every departing
     agent and of every alternative of every agent in front of a switch, then the epsilon-greedy choice on the
     device (flm_policy_select).  `last` holds what the replay memory needs: a list with one group
-    (agents e*A+a, their observations as shown to the network, the actions chosen)."""
+    (agents e*A+a, their observations as shown to the network, the actions chosen).  `raw` are views of buffers
+    that the next call overwrites."""
 
     def __init__(self, agent, eps=0.0, seed=0, chunk_bytes=2 << 30):
         if agent.action_space != 2:                        # the rollout's decision is stop (0) or go (1), src/main.py:163-213
@@ -54,8 +55,9 @@ class DQNPolicy:
         self.seed = int(seed) & 0xFFFFFFFF
         self._raw = None
         self._last = None
+        self._flat = self._sel = self._pool = None
 
-    def q_values(self, ro, obs_u8):
+    def q_values(self, ro, obs_u8, out=None, flat=None):
         b = ro.b
         n = obs_u8.shape[0]
         per = 64 * 3 * b.Rp * 4                            # the convolution output dominates the workspace
@@ -63,12 +65,29 @@ class DQNPolicy:
         net = self.agent.qnetwork_local
         rails = ro.rails_used()                            # rails beyond these are padding in every observation
         if n <= chunk:
-            return net.forward_obs(obs_u8, b.plane_stride, rails)
-        q = torch.empty((n, 2), dtype=torch.float32, device=obs_u8.device)
+            return net.forward_obs(obs_u8, b.plane_stride, rails, out=out, flat=flat)
+        q = torch.empty((n, 2), dtype=torch.float32, device=obs_u8.device) if out is None else out[:n]
         for lo in range(0, n, chunk):
             hi = min(n, lo + chunk)
-            q[lo:hi] = net.forward_obs(obs_u8[lo:hi], b.plane_stride, rails)
+            net.forward_obs(obs_u8[lo:hi], b.plane_stride, rails, out=q[lo:hi], flat=flat)
         return q
+
+    def prepare(self, ro):
+        """Host work of the coming call that needs none of the step's sizes; RolloutBatch.step calls it before it
+        waits for them, while the device is still busy."""
+        self._flat = self.agent.qnetwork_local.flat_params()
+        if self._sel is None or self._sel[0].numel() < ro.E * ro.A or self._sel[0].device != ro.device:
+            self._sel = tuple(torch.empty((ro.E * ro.A,), dtype=torch.int32, device=ro.device) for _ in range(2))
+
+    def _rows_pool(self, ro, rows):
+        """Observation rows and Q-values of a step: buffers that only grow."""
+        pool = self._pool
+        if pool is None or pool[0].shape[0] < rows or pool[0].device != ro.device:
+            self._pool = pool = None                        # (release before taking larger ones)
+            cap = rows + rows // 4 + 64
+            self._pool = pool = (torch.empty((cap, 3, ro.b.plane_stride), dtype=torch.uint8, device=ro.device),
+                                 torch.empty((cap, 2), dtype=torch.float32, device=ro.device))
+        return pool
 
     def __call__(self, ro, info):
         net, best = info["net"], info["best"]
@@ -77,18 +96,23 @@ class DQNPolicy:
         self._raw = self._last = None
         if n1 + n2 == 0:
             return net, best
+        if self._flat is None:
+            self.prepare(ro)
+        flat, self._flat = self._flat, None
         if alt is not None:
             rows = ro.read_counts()[2]                     # departing agents + all alternatives
-            obs = ro.consult_observations(alt["row_req"][:rows], alt["cols"].view(-1, ro.b.T1), own_row=alt["row_own"][:rows]) \
-                if rows else None
+            if rows:
+                obs_pool, q_pool = self._rows_pool(ro, rows)
+                obs = ro.consult_observations(alt["row_req"][:rows], alt["cols"].view(-1, ro.b.T1), out=obs_pool[:rows],
+                                              own_row=alt["row_own"][:rows])
         else:
             rows = n1
-            obs = ro.consult_observations(req1)
+            obs_pool, q_pool = self._rows_pool(ro, rows)
+            obs = ro.consult_observations(req1, out=obs_pool[:rows])
         if rows == 0:                                       # agents before a switch, none with an alternative
             return net, best
-        q = self.q_values(ro, obs)
-        sel_row = torch.empty((n1 + n2,), dtype=torch.int32, device=ro.device)
-        sel_act = torch.empty((n1 + n2,), dtype=torch.int32, device=ro.device)
+        q = self.q_values(ro, obs, out=q_pool, flat=flat)
+        sel_row, sel_act = self._sel[0][:n1 + n2], self._sel[1][:n1 + n2]
         call("flm_policy_select", ptr(q), ptr(req1) if n1 else None, n1, ptr(req2) if n2 else None, n2,
              ptr(alt["row_offset"]) if alt is not None else None, ptr(alt["count"]) if alt is not None else None,
              self.eps, self.seed, int(info["t"]), ptr(net), ptr(best), ptr(sel_row), ptr(sel_act), ro.stream)
