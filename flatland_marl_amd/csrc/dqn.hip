@@ -1646,20 +1646,7 @@ __global__ __launch_bounds__(256) void fc1_wgrad_padding_kernel(const float* __r
 
 // ... and the convolution's bias gradient gains, for every filter that is active on an empty row (conv_b[c] > 0), the
 // sum over those rows of the activation gradient: sum over o of gsum[o] * wpad[c][o] (wpad: fc1_padding_bias_kernel).
-// One workgroup per filter: thread t sums o = t, t + 256, ..., the partial sums meet in LDS in a fixed order.
-__global__ __launch_bounds__(256) void conv_bias_padding_kernel(const float* __restrict__ gsum, const float* __restrict__ wpad,
-                                                                const float* __restrict__ conv_b, float* __restrict__ db) {
-  __shared__ float sm[256];
-  const int c = blockIdx.x, t = threadIdx.x;
-  const float* wp = wpad + (long)c * 1024;
-  sm[t] = (gsum[t] * wp[t] + gsum[t + 256] * wp[t + 256]) + (gsum[t + 512] * wp[t + 512] + gsum[t + 768] * wp[t + 768]);
-  __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
-    if (t < st) sm[t] += sm[t + st];
-    __syncthreads();
-  }
-  if (t == 0 && conv_b[c] > 0.f) db[c] += sm[0];
-}
+// conv_wgrad_reduce_kernel adds it where it writes the bias gradient.
 
 // ---- the convolution's weight and bias gradients straight from uint8 observations --------------------------------
 // dWc[c][k] = sum over samples b and rows h of dx1[b][c][h] * s[b][h][k],  dbias[c] = sum of dx1[b][c][h].
@@ -1804,10 +1791,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_u8_kernel(const float* __re
 }
 
 // dW[c][k] (k < T1) and db[c] (k == T1) = sum over the G workgroup partials part[g][c][k] of row width W: sixteen waves
-// take every sixteenth partial each (two sums in flight per lane), their sums meet in LDS in wave order
+// take every sixteenth partial each (two sums in flight per lane), their sums meet in LDS in wave order.
+// gsum != nullptr (learn step over the used rails): the workgroup that holds the bias element of a filter with
+// conv_b[c] > 0 also adds the empty rows' share, sum over o of gsum[o] * wpad[c][o]: thread t < 256 takes o = t, t + 256,
+// t + 512, t + 768, the 256 partial sums meet in LDS by halving.
 __global__ __launch_bounds__(1024) void conv_wgrad_reduce_kernel(const float* __restrict__ part, int G, int W, int T1,
-                                                                 float* __restrict__ dW, float* __restrict__ db) {
+                                                                 float* __restrict__ dW, float* __restrict__ db,
+                                                                 const float* __restrict__ gsum, const float* __restrict__ wpad,
+                                                                 const float* __restrict__ conv_b) {
   __shared__ float sm[16][64];
+  __shared__ float pad[256], padv[64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + lane;
   const bool valid = idx < 64 * (T1 + 1);
@@ -1822,13 +1815,33 @@ __global__ __launch_bounds__(1024) void conv_wgrad_reduce_kernel(const float* __
   }
   if (g < G) s0 += p[(size_t)g * gs];
   sm[w][lane] = s0 + s1;
+  // the bias element of filter cb lies at index cb*(T1+1) + T1: those among this workgroup's 64 indices, one by one
+  // (the loop is the same for the whole workgroup)
+  const int first = blockIdx.x * 64, t = threadIdx.x;
+  if (gsum != nullptr) {
+    for (int cb = first / (T1 + 1); cb < 64; cb++) {          // (the smallest cb with cb*(T1+1) + T1 >= first)
+      const int at = cb * (T1 + 1) + T1;
+      if (at >= first + 64) break;
+      if (t < 256) {
+        const float* wp = wpad + (long)cb * 1024;
+        pad[t] = (gsum[t] * wp[t] + gsum[t + 256] * wp[t + 256]) + (gsum[t + 512] * wp[t + 512] + gsum[t + 768] * wp[t + 768]);
+      }
+      __syncthreads();
+      for (int st = 128; st > 0; st >>= 1) {
+        if (t < st) pad[t] += pad[t + st];
+        __syncthreads();
+      }
+      if (t == 0) padv[at - first] = pad[0];
+      __syncthreads();
+    }
+  }
   __syncthreads();
   if (w == 0 && valid) {
     float v = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; i++) v += sm[i][lane];
     if (k < T1) dW[(size_t)c * T1 + k] = v;
-    else db[c] = v;
+    else db[c] = gsum != nullptr && conv_b[c] > 0.f ? v + padv[lane] : v;
   }
 }
 
@@ -1839,13 +1852,14 @@ static int conv_wgrad_u8_groups(int B) { return B < 256 ? B : 256; }
 
 template <int NT>
 static int launch_conv_wgrad_u8(const float* dx1, const uint8_t* obs, int B, int Rp, int T1, int plane_stride, float* part,
-                                float* dW, float* db, hipStream_t stream) {
+                                float* dW, float* db, hipStream_t stream, const float* gsum = nullptr,
+                                const float* wpad = nullptr, const float* conv_b = nullptr) {
   const int G = conv_wgrad_u8_groups(B);
   const size_t lds = (size_t)6 * NT * 16 * 64 * sizeof(float);
   FLM_RAISE_LDS_ONCE((conv_wgrad_u8_kernel<NT>));
   hipLaunchKernelGGL((conv_wgrad_u8_kernel<NT>), dim3(G), dim3(512), lds, stream, dx1, obs, B, Rp, T1, plane_stride, part);
   hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((64 * (T1 + 1) + 63) / 64)), dim3(1024), 0, stream, part, G,
-                     32 * NT, T1, dW, db);
+                     32 * NT, T1, dW, db, gsum, wpad, conv_b);
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
 }
@@ -2246,7 +2260,7 @@ static int learn_dense_half(const float* local, const float* target, const float
   int rc;
   // R4 > 0 (uint8 observations only): rails [R4, Rp) are empty in every plane of every observation; the convolutions and
   // the products of the first dense layer run over the used rails (activations [.,64,3*R4]), the empty ones enter in
-  // closed form (fc1_padding_bias_kernel, fc1_wgrad_padding_kernel, conv_bias_padding_kernel)
+  // closed form (fc1_padding_bias_kernel, fc1_wgrad_padding_kernel, conv_wgrad_reduce_kernel's bias share)
   const int Rp = H3 / 3;
   const int H3c = R4 ? 3 * R4 : H3;                 // rows per sample the convolution computes
   const long n_x1c = (long)B * 64 * H3c;
@@ -2381,16 +2395,15 @@ static int learn_conv_half(const float* local, const float* s, const uint8_t* s_
     float* dW = grads + L.conv_w;
     float* db = grads + L.conv_b;
     const int rails = R4 ? R4 : Rp;          // rails per plane in dx1 (the kernel steps through the planes by plane_stride)
+    // (over the used rails the bias gradient's share of the empty rows rides in the reduction)
+    const float* gs = R4 ? w.gsum : nullptr;
+    const float* cb = local + L.conv_b;
     switch (nt) {
-      case 1: rc = flm::launch_conv_wgrad_u8<1>(w.dx1, s_u8, B, rails, T1, plane_stride, w.cpart, dW, db, stream); break;
-      case 2: rc = flm::launch_conv_wgrad_u8<2>(w.dx1, s_u8, B, rails, T1, plane_stride, w.cpart, dW, db, stream); break;
-      case 3: rc = flm::launch_conv_wgrad_u8<3>(w.dx1, s_u8, B, rails, T1, plane_stride, w.cpart, dW, db, stream); break;
-      case 4: rc = flm::launch_conv_wgrad_u8<4>(w.dx1, s_u8, B, rails, T1, plane_stride, w.cpart, dW, db, stream); break;
-      default: rc = flm::launch_conv_wgrad_u8<5>(w.dx1, s_u8, B, rails, T1, plane_stride, w.cpart, dW, db, stream); break;
-    }
-    if (rc == FLM_OK && R4) {
-      hipLaunchKernelGGL(flm::conv_bias_padding_kernel, dim3(64), dim3(256), 0, stream, w.gsum, w.wpad, local + L.conv_b, db);
-      if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
+      case 1: rc = flm::launch_conv_wgrad_u8<1>(w.dx1, s_u8, B, rails, T1, plane_stride, w.cpart, dW, db, stream, gs, w.wpad, cb); break;
+      case 2: rc = flm::launch_conv_wgrad_u8<2>(w.dx1, s_u8, B, rails, T1, plane_stride, w.cpart, dW, db, stream, gs, w.wpad, cb); break;
+      case 3: rc = flm::launch_conv_wgrad_u8<3>(w.dx1, s_u8, B, rails, T1, plane_stride, w.cpart, dW, db, stream, gs, w.wpad, cb); break;
+      case 4: rc = flm::launch_conv_wgrad_u8<4>(w.dx1, s_u8, B, rails, T1, plane_stride, w.cpart, dW, db, stream, gs, w.wpad, cb); break;
+      default: rc = flm::launch_conv_wgrad_u8<5>(w.dx1, s_u8, B, rails, T1, plane_stride, w.cpart, dW, db, stream, gs, w.wpad, cb); break;
     }
     return rc;
   }

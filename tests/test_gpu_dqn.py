@@ -201,11 +201,14 @@ def test_gradients_elementwise_vs_torch(B, H3, T1):
 
 
 @pytest.mark.parametrize("NA,B,H3,T1,double_dqn", [(1, 20, 12, 21, True), (3, 40, 30, 21, True), (5, 130, 9, 151, True),
-                                                   (16, 33, 21, 37, True), (4, 24, 15, 31, False)])
+                                                   (16, 33, 21, 37, True), (4, 24, 15, 31, False),
+                                                   (2, 1024, 9, 21, True), (3, 1100, 9, 21, True)])
 def test_other_action_spaces_elementwise_vs_torch(NA, B, H3, T1, double_dqn):
     """action_space other than the training script's 2 (the constructor argument of src/model.py:11 and
     src/agent.py:17): state_dict shapes, Q-values, loss and every gradient element against plain PyTorch fp32, for the
-    double-DQN target and the reference's plain branch with its [B,B] broadcast.  The reference's own goldens hold two actions only: these sizes are checked against PyTorch alone."""
+    double-DQN target and the reference's plain branch with its [B,B] broadcast.  The reference's own goldens hold two
+    actions only: these sizes are checked against PyTorch alone.  (Batches of 1024 and 1100: the largest that the
+    one-launch form of the loss and the head's backward pass takes, and the separate kernels beyond it.)"""
     import torch.nn.functional as F
     from flatland_marl_amd.agent import DQNAgent
     from tests.torch_ref_dqn import TorchDuelingDQN
