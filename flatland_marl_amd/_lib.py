@@ -62,8 +62,8 @@ _SIGNATURES = {
     "flm_dqn_learn_grads_u8_rails": [_p, _p, _p, _p, _i, _p, _p, _p, C.c_float, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p],
     "flm_dqn_learn_rails_rcb_offset": [_i, _i, _i, _i],
     "flm_dqn_adam_soft_update_rails": [_p, _p, _p, _p, _p, C.c_long, C.c_double, C.c_double, C.c_double, C.c_double, _i,
-                                       C.c_double, _i, _i, _i, _i, _p, _p, _p, _p],
-    "flm_dqn_adam_moments": [_p, _p, C.c_long, _i, _i, _i, _i, _p, _i, _p],
+                                       C.c_double, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
+    "flm_dqn_adam_moments": [_p, _p, C.c_long, _i, _i, _i, _i, _p, _p, _p, _i, _p],
     "flm_dqn_forward": [_p, _p, _i, _i, _i, _i, _p, _p, _p],
     "flm_obs_to_f32": [_p, _i, _i, _i, _i, _p, _p],
     "flm_dqn_forward_u8": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p],

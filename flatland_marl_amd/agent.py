@@ -25,9 +25,10 @@ class FlatAdam:
 
     The moments m and v are flat buffers like the parameters.  While every step since they were zero has been a learn
     step over the used rails, the moments of the first dense layer's weights under the empty rows are equal along the
-    rows; they are then kept once per (output unit, filter) in a small buffer and the large ones are left stale there
-    (flm_dqn_adam_soft_update_rails with moments_in / moments_out: a third less memory traffic, the same bits).
-    Reading .m or .v brings the large buffers up to date and ends that form for good: whoever holds them may write."""
+    rows; the optimizer then keeps its data of the two weight blocks in the compact form of
+    flm_dqn_adam_soft_update_rails (one pair of moments per (output unit, filter) for the empty rows, packed moments and
+    a packed gradient for the used ones: two thirds of the memory traffic, the same bits) and leaves the large buffers
+    stale there.  Reading .m or .v brings them up to date and ends that form for good: whoever holds them may write."""
 
     def __init__(self, network, lr, betas=(0.9, 0.999), eps=1e-8):
         self.network = network
@@ -35,7 +36,8 @@ class FlatAdam:
         self.step_count = 0
         self._m = self._v = self.grads = None
         self._pairs = None                  # two buffers [2*512*64, 2] (m, v) under the empty rows; [0] is current
-        self._compact = None                # (Rp, T1, NA, rails4) while the large buffers are stale under rails >= rails4
+        self._packed = None                 # (m, v) under the used rails, [2*512*64*3*rails4] each
+        self._compact = None                # (Rp, T1, NA, rails4) while the large buffers are stale in the weight blocks
         self._uniform_from = 0              # moments known equal along the rows from this rail on (None: not known)
 
     def _ensure(self):
@@ -44,15 +46,17 @@ class FlatAdam:
             self._m = torch.zeros_like(flat)
             self._v = torch.zeros_like(flat)
             self.grads = torch.zeros_like(flat)
-            self._compact, self._uniform_from, self._pairs = None, 0, None
+            self._compact, self._uniform_from, self._pairs, self._packed = None, 0, None, None
         return flat
+
+    def _moments(self, key, fill):
+        call("flm_dqn_adam_moments", ptr(self._m), ptr(self._v), self._m.numel(), *key, ptr(self._pairs[0]),
+             ptr(self._packed[0]), ptr(self._packed[1]), fill, torch.cuda.current_stream(self._m.device).cuda_stream)
 
     def _spread(self):
         """The large moment buffers up to date again."""
         if self._compact is not None:
-            Rp, T1, NA, rails4 = self._compact
-            call("flm_dqn_adam_moments", ptr(self._m), ptr(self._v), self._m.numel(), Rp, T1, NA, rails4, ptr(self._pairs[0]),
-                 1, torch.cuda.current_stream(self._m.device).cuda_stream)
+            self._moments(self._compact, 1)
             self._compact = None
 
     @property
@@ -71,31 +75,46 @@ class FlatAdam:
         self._ensure()
         self.grads.zero_()
 
+    def compact_for(self, Rp, T1, NA, rails4):
+        """Whether the next step(rails=...) with these sizes will run in the compact form: the learn step then has to
+        leave the two weight blocks' gradient packed (fill_padding = 2)."""
+        self._ensure()
+        return self._uniform_from is not None and self._uniform_from <= int(rails4)
+
     def step(self, target=None, tau=None, rails=None):
         """One Adam step; with target (the target network's flat parameters) and tau also its soft update with
-        the new parameters, in the same pass.  rails = (Rp, T1, NA, rails4, rcb): the learn step ran over the used
-        rails and left the first dense layer's gradient under the empty rows to this pass
-        (flm_dqn_adam_soft_update_rails)."""
+        the new parameters, in the same pass.  rails = (Rp, T1, NA, rails4, rcb, packed): the learn step ran over the
+        used rails and left the first dense layer's gradient under the empty rows to this pass
+        (flm_dqn_adam_soft_update_rails); packed: it left the rest of that gradient in the packed form, as it must
+        exactly when compact_for(...) said so."""
         flat = self._ensure()
         self.step_count += 1
         st = torch.cuda.current_stream(flat.device).cuda_stream
         hyper = (float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_count)
         if target is not None and rails is not None:
-            Rp, T1, NA, rails4, rcb = rails
+            Rp, T1, NA, rails4, rcb, packed = rails
             key = (int(Rp), int(T1), int(NA), int(rails4))
+            if bool(packed) != self.compact_for(*key):
+                raise ValueError("the gradient's form does not match the optimizer's (ask compact_for before the learn step)")
             if self._compact is not None and self._compact != key:
                 self._spread()
-            if self._compact is None and self._uniform_from is not None and self._uniform_from <= rails4:
+            if packed and self._compact is None:
+                dev = flat.device
                 if self._pairs is None:
-                    self._pairs = [torch.empty((2 * 512 * 64, 2), dtype=torch.float32, device=flat.device) for _ in range(2)]
-                call("flm_dqn_adam_moments", ptr(self._m), ptr(self._v), flat.numel(), *key, ptr(self._pairs[0]), 0, st)
+                    self._pairs = [torch.empty((2 * 512 * 64, 2), dtype=torch.float32, device=dev) for _ in range(2)]
+                n_packed = 2 * 512 * 64 * 3 * key[3]
+                if self._packed is None or self._packed[0].numel() != n_packed:
+                    self._packed = None
+                    self._packed = tuple(torch.empty((n_packed,), dtype=torch.float32, device=dev) for _ in range(2))
+                self._moments(key, 0)
                 self._compact = key
             if self._uniform_from is not None:
-                self._uniform_from = max(self._uniform_from, int(rails4))
-            pairs = (ptr(self._pairs[0]), ptr(self._pairs[1])) if self._compact is not None else (None, None)
+                self._uniform_from = max(self._uniform_from, key[3])
+            extra = (ptr(self._pairs[0]), ptr(self._pairs[1]), ptr(self._packed[0]), ptr(self._packed[1])) if packed \
+                else (None, None, None, None)
             call("flm_dqn_adam_soft_update_rails", ptr(flat), ptr(self.grads), ptr(self._m), ptr(self._v), ptr(target),
-                 flat.numel(), *hyper, float(tau), *key, ptr(rcb), *pairs, st)
-            if self._compact is not None:
+                 flat.numel(), *hyper, float(tau), *key, ptr(rcb), *extra, st)
+            if packed:
                 self._pairs.reverse()
             return
         # any other step gives the weights under the empty rows gradients of their own
@@ -207,15 +226,16 @@ class DQNAgent:
         # weight blocks' indices stay below 2^24)
         rails4 = query("flm_dqn_learn_rails", B, Rp, self.width, int(rails_used))
         fused = rails4 > 0 and type(self).soft_update is DQNAgent.soft_update and 512 * 64 * self.height < (1 << 24)
+        packed = fused and self.optimizer.compact_for(Rp, self.width, self.action_space, rails4)
         args = (ptr(local), ptr(target), ptr(s), ptr(sn), int(plane_stride), ptr(a), ptr(r), ptr(d),
                 float(gamma), 1 if self.double_dqn else 0, B, Rp, self.width, self.action_space, int(rails_used),
-                ptr(self._ws), ptr(self.optimizer.grads), ptr(loss), 0 if fused else 1)
+                ptr(self._ws), ptr(self.optimizer.grads), ptr(loss), (2 if packed else 0) if fused else 1)
         self._grads_and_exchange("flm_dqn_learn_grads_u8_rails", args, st, phased_entry=True)
         self.last_loss = loss
         if fused:
             off = query("flm_dqn_learn_rails_rcb_offset", B, Rp, self.width, self.action_space)
             self.optimizer.step(target=target, tau=self.args.tau,
-                                rails=(Rp, self.width, self.action_space, rails4, self._ws[off:off + 64]))
+                                rails=(Rp, self.width, self.action_space, rails4, self._ws[off:off + 64], packed))
         else:
             self._update(target)
 

@@ -1139,18 +1139,22 @@ __device__ __forceinline__ unsigned div_small(unsigned n, unsigned d, float inv_
   else if ((q + 1) * d <= n) q++;
   return q;
 }
-// COMPACT: the two moments of the weights under the empty rows are kept once per (output unit, filter) instead of
-// once per weight.  Those weights have received the same gradient in every step so far (the caller's condition), so
-// their moments are the same along the rows: mv_in [2][512][64] pairs (m, v) holds them, the pass reads them from
-// there, leaves m and v under the empty rows alone and writes the new pair to mv_out (another buffer: other threads are
-// still reading mv_in).  The parameters and the target are updated element by element as before: the same bits.
+// COMPACT: the optimizer's own data of the first dense layer's weights (moments and gradient) is kept without the
+// empty rows.  (a) The weights under the empty rows have received the same gradient in every step so far (the caller's
+// condition), so their moments are the same along the rows: mv_in [2][512][64] pairs (m, v) holds them once per
+// (stream, output unit, filter); the pass reads them from there and writes the new pair to mv_out (another buffer:
+// other threads are still reading mv_in).  (b) The moments under the used rails live in mpk / vpk [2][512][Kc]
+// (Kc = 64*3*R4 columns: filter, plane, rail < R4), and the gradient is read in the same packed form from the start of
+// each weight block of g, as the learn step leaves it when asked to.  m and v of the two weight blocks are not touched:
+// reading 20 floats out of every 70 moves nearly every 128-byte line anyway, the packed form moves a third.
+// The parameters and the target are updated element by element as before: the same bits.
 template <bool COMPACT>
 __global__ __launch_bounds__(256) void adam_soft_update_rails_kernel(
     float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
     float* __restrict__ target, long n, float one_minus_b1, float beta2, float one_minus_b2, float eps, float step_size,
     float bc2_sqrt, float tau, float one_minus_tau, long a1_w, long a1_b, long v1_w, long v1_b, unsigned K1, unsigned H3,
     unsigned Rp, unsigned R4, float inv_K1, float inv_H3, float inv_Rp, const float* __restrict__ rcb,
-    const float2* __restrict__ mv_in, float2* __restrict__ mv_out) {
+    const float2* __restrict__ mv_in, float2* __restrict__ mv_out, float* __restrict__ mpk, float* __restrict__ vpk) {
   // four consecutive parameters per thread (the two weight blocks start and end on multiples of four, so a thread's
   // four lie inside one or outside both): their place (output unit, filter, rail) is worked out once and stepped
   const long i0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -1168,15 +1172,16 @@ __global__ __launch_bounds__(256) void adam_soft_update_rails_kernel(
     rail = r2 - pl * Rp;
   }
   const float* gb = g + (adv ? a1_b : v1_b);
-  const bool whole = i0 + 3 < n;
+  const unsigned Kc = 192u * R4;
   float pv[4], mv[4], vv[4], tv[4], gv[4];
   bool synth[4], owner[4];
-  unsigned pair[4];
+  unsigned pair[4], pk[4];
 #pragma unroll
   for (int e = 0; e < 4; e++) {
     synth[e] = (adv || val) && rail >= R4;
     gv[e] = synth[e] ? rcb[c] * gb[o] : 0.f;
     pair[e] = ((adv ? 0u : 512u) + o) * 64u + c;
+    pk[e] = o * Kc + (c * 3u + pl) * R4 + rail;               // (meaningful under the used rails)
     owner[e] = synth[e] && pl == 0 && rail == R4;
     if (++rail == Rp) {
       rail = 0;
@@ -1186,18 +1191,52 @@ __global__ __launch_bounds__(256) void adam_soft_update_rails_kernel(
       }
     }
   }
-  const bool all_synth = synth[0] && synth[1] && synth[2] && synth[3];
-  const bool moments = !(COMPACT && all_synth);            // this thread reads and writes m and v
-  if (whole) {
+  if (COMPACT && (adv || val)) {
     const float4 p4 = *reinterpret_cast<const float4*>(p + i0), t4 = *reinterpret_cast<const float4*>(target + i0);
     pv[0] = p4.x; pv[1] = p4.y; pv[2] = p4.z; pv[3] = p4.w;
     tv[0] = t4.x; tv[1] = t4.y; tv[2] = t4.z; tv[3] = t4.w;
-    if (moments) {
-      const float4 m4 = *reinterpret_cast<const float4*>(m + i0), v4 = *reinterpret_cast<const float4*>(v + i0);
-      mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
-      vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
+    const float* gp = g + (adv ? a1_w : v1_w);
+    float* mp = mpk + (adv ? 0 : (size_t)512 * Kc);
+    float* vp = vpk + (adv ? 0 : (size_t)512 * Kc);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      if (synth[e]) {
+        const float2 mvp = mv_in[pair[e]];
+        mv[e] = mvp.x;
+        vv[e] = mvp.y;
+      } else {
+        gv[e] = gp[pk[e]];
+        mv[e] = mp[pk[e]];
+        vv[e] = vp[pk[e]];
+      }
     }
-    if (!all_synth) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      adam_element(pv[e], gv[e], mv[e], vv[e], k);
+      tv[e] = soft_element(pv[e], tv[e], k);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      if (!synth[e]) {
+        mp[pk[e]] = mv[e];
+        vp[pk[e]] = vv[e];
+      } else if (owner[e]) {
+        mv_out[pair[e]] = make_float2(mv[e], vv[e]);
+      }
+    }
+    *reinterpret_cast<float4*>(p + i0) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+    *reinterpret_cast<float4*>(target + i0) = make_float4(tv[0], tv[1], tv[2], tv[3]);
+    return;
+  }
+  const bool whole = i0 + 3 < n;
+  if (whole) {
+    const float4 p4 = *reinterpret_cast<const float4*>(p + i0), t4 = *reinterpret_cast<const float4*>(target + i0);
+    const float4 m4 = *reinterpret_cast<const float4*>(m + i0), v4 = *reinterpret_cast<const float4*>(v + i0);
+    pv[0] = p4.x; pv[1] = p4.y; pv[2] = p4.z; pv[3] = p4.w;
+    tv[0] = t4.x; tv[1] = t4.y; tv[2] = t4.z; tv[3] = t4.w;
+    mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
+    vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
+    if (!(synth[0] && synth[1] && synth[2] && synth[3])) {
       const float4 g4 = *reinterpret_cast<const float4*>(g + i0);
       if (!synth[0]) gv[0] = g4.x;
       if (!synth[1]) gv[1] = g4.y;
@@ -1214,32 +1253,16 @@ __global__ __launch_bounds__(256) void adam_soft_update_rails_kernel(
         pv[e] = mv[e] = vv[e] = tv[e] = gv[e] = 0.f;
       }
   }
-  if (COMPACT) {
-#pragma unroll
-    for (int e = 0; e < 4; e++)
-      if (synth[e]) {
-        const float2 mvp = mv_in[pair[e]];
-        mv[e] = mvp.x;
-        vv[e] = mvp.y;
-      }
-  }
 #pragma unroll
   for (int e = 0; e < 4; e++) {
     adam_element(pv[e], gv[e], mv[e], vv[e], k);
     tv[e] = soft_element(pv[e], tv[e], k);
   }
-  if (COMPACT) {
-#pragma unroll
-    for (int e = 0; e < 4; e++)
-      if (owner[e]) mv_out[pair[e]] = make_float2(mv[e], vv[e]);
-  }
   if (whole) {
     *reinterpret_cast<float4*>(p + i0) = make_float4(pv[0], pv[1], pv[2], pv[3]);
     *reinterpret_cast<float4*>(target + i0) = make_float4(tv[0], tv[1], tv[2], tv[3]);
-    if (moments) {
-      *reinterpret_cast<float4*>(m + i0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
-      *reinterpret_cast<float4*>(v + i0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-    }
+    *reinterpret_cast<float4*>(m + i0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+    *reinterpret_cast<float4*>(v + i0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
   } else {
 #pragma unroll
     for (int e = 0; e < 4; e++)
@@ -1247,30 +1270,37 @@ __global__ __launch_bounds__(256) void adam_soft_update_rails_kernel(
   }
 }
 
-// The moments under the empty rows, between their two forms.  take: pair[(stream, o, c)] = (m, v) of that unit and
-// filter at plane 0, rail R4 (one of the equal ones).  fill: every m and v under the empty rows from its pair.
-__global__ __launch_bounds__(256) void adam_moments_take_kernel(const float* __restrict__ m, const float* __restrict__ v,
-                                                                long a1_w, long v1_w, long K1, int H3, int R4,
-                                                                float2* __restrict__ pairs) {
-  const int i = blockIdx.x * 256 + threadIdx.x;               // (stream*512 + o)*64 + c
-  if (i >= 2 * 512 * 64) return;
-  const int c = i & 63, o = (i >> 6) & 511;
-  const long at = (i >= 512 * 64 ? v1_w : a1_w) + (long)o * K1 + (long)c * H3 + R4;
-  pairs[i] = make_float2(m[at], v[at]);
-}
-__global__ __launch_bounds__(256) void adam_moments_fill_kernel(float* __restrict__ m, float* __restrict__ v, long a1_w, long v1_w,
-                                                                long K1, int H3, int Rp, int R4,
-                                                                const float2* __restrict__ pairs) {
-  const int o = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;      // o: stream*512 + unit
+// The optimizer's moments of the two weight blocks, between their two forms.  One workgroup per (stream, output unit).
+// take: pair[(stream, o, c)] = (m, v) at plane 0, rail R4 (one of the equal ones under the empty rows), and the moments
+// under the used rails into mpk / vpk [2][512][Kc].  fill: the other way, every m and v under the empty rows from its pair.
+template <bool FILL>
+__global__ __launch_bounds__(256) void adam_moments_kernel(float* __restrict__ m, float* __restrict__ v, long a1_w, long v1_w,
+                                                           long K1, int H3, int Rp, int R4, float2* __restrict__ pairs,
+                                                           float* __restrict__ mpk, float* __restrict__ vpk) {
+  const int o = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;      // o: stream*512 + unit
   const long base = (o < 512 ? a1_w + (long)o * K1 : v1_w + (long)(o - 512) * K1);
+  const long Kc = 192L * R4;
   const int L = Rp - R4;
-  for (int sg = w; sg < 192; sg += 4) {
+  for (int sg = w; sg < 192; sg += 4) {                                        // segment = (filter, plane)
     const int c = sg / 3, pl = sg - 3 * c;
-    const float2 mvp = pairs[o * 64 + c];
-    const long at = base + (long)c * H3 + (long)pl * Rp + R4;
-    for (int i = lane; i < L; i += 64) {
-      m[at + i] = mvp.x;
-      v[at + i] = mvp.y;
+    const long at = base + (long)c * H3 + (long)pl * Rp;
+    const long pat = (long)o * Kc + (long)sg * R4;
+    if (FILL) {
+      const float2 mvp = pairs[o * 64 + c];
+      for (int i = lane; i < L; i += 64) {
+        m[at + R4 + i] = mvp.x;
+        v[at + R4 + i] = mvp.y;
+      }
+      for (int i = lane; i < R4; i += 64) {
+        m[at + i] = mpk[pat + i];
+        v[at + i] = vpk[pat + i];
+      }
+    } else {
+      if (pl == 0 && lane == 0) pairs[o * 64 + c] = make_float2(m[at + R4], v[at + R4]);
+      for (int i = lane; i < R4; i += 64) {
+        mpk[pat + i] = m[at + i];
+        vpk[pat + i] = v[at + i];
+      }
     }
   }
 }
@@ -2345,10 +2375,18 @@ static int learn_dense_half(const float* local, const float* target, const float
     const long Kc = 192L * R4;
     g.N = (int)Kc; g.ldb = Kc;
     g.b_seg_len = R4; g.b_seg_stride = Rp; g.b_seg_magic = (unsigned)((0x100000000ULL + (unsigned)R4 - 1) / (unsigned)R4);
-    if ((rc = flm::launch_gemm<false, false, flm::EPI_PLAIN, 3>(g, 2, stream))) return rc;
-    if (fill_padding)     // (otherwise the optimizer pass forms these products itself: flm_dqn_adam_soft_update_rails)
-      hipLaunchKernelGGL(flm::fc1_wgrad_padding_kernel, dim3(1024), dim3(256), 0, stream, w.gsum, local + L.conv_b,
-                         grads + L.a1_w, grads + L.v1_w, L.K1, H3, Rp, R4);
+    if (fill_padding == 2) {
+      // packed: the product as it is, [512][Kc] at the start of each weight block of grads (the optimizer pass in its
+      // compact form reads it there and forms the gradient under the empty rows itself)
+      g.ldc = Kc;
+      g.b_seg_len = 0;
+      if ((rc = flm::launch_gemm<false, false, flm::EPI_PLAIN>(g, 2, stream))) return rc;
+    } else {
+      if ((rc = flm::launch_gemm<false, false, flm::EPI_PLAIN, 3>(g, 2, stream))) return rc;
+      if (fill_padding)     // (otherwise the optimizer pass forms these products itself: flm_dqn_adam_soft_update_rails)
+        hipLaunchKernelGGL(flm::fc1_wgrad_padding_kernel, dim3(1024), dim3(256), 0, stream, w.gsum, local + L.conv_b,
+                           grads + L.a1_w, grads + L.v1_w, L.K1, H3, Rp, R4);
+    }
   } else {
     if ((rc = flm::launch_gemm<false, false, flm::EPI_PLAIN>(g, 2, stream))) return rc;
   }
@@ -2507,11 +2545,12 @@ extern "C" int flm_dqn_learn_grads_u8_rails(const float* local, const float* tar
                                             void* stream) {
   if (!local || !target || !s || !s_next || !action || !reward || !done || !ws || !grads || !loss_out) return FLM_E_ARG;
   if (B <= 0 || Rp <= 0 || T1 <= 0 || (long)plane_stride < (long)Rp * T1 || !actions_ok(NA) || phase < 0 || phase > 2 ||
-      rails_used < 0 || rails_used > Rp)
+      rails_used < 0 || rails_used > Rp || fill_padding < 0 || fill_padding > 2)
     return FLM_E_ARG;
   const int H3 = 3 * Rp;
   // the used-rails form needs the byte form of the convolution's weight gradient (no float copy of the states exists)
   const int R4 = (int)flm_dqn_learn_rails(B, Rp, T1, rails_used);
+  if (fill_padding != 1 && !R4) return FLM_E_ARG;
   float* s_f32 = ws + flm_dqn_learn_workspace(B, H3, T1, NA);
   return learn_grads_impl(local, target, s_f32, nullptr, s, s_next, plane_stride, action, reward, done, gamma, double_dqn, B,
                           H3, T1, NA, ws, grads, loss_out, (hipStream_t)stream, phase, R4, fill_padding);
@@ -2554,14 +2593,15 @@ extern "C" long flm_dqn_learn_rails_rcb_offset(int B, int Rp, int T1, int NA) {
 extern "C" int flm_dqn_adam_soft_update_rails(float* params, const float* grads, float* m, float* v, float* target, long n,
                                               double lr, double beta1, double beta2, double eps, int step, double tau, int Rp,
                                               int T1, int NA, int rails4, const float* rcb, const float* moments_in,
-                                              float* moments_out, void* stream) {
+                                              float* moments_out, float* m_packed, float* v_packed, void* stream) {
   if (!params || !grads || !m || !v || !target || !rcb || n <= 0 || step <= 0 || Rp <= 0 || T1 <= 0 || !actions_ok(NA))
     return FLM_E_ARG;
   const DqnLayout L(3 * Rp, T1, NA);
   if (n != L.total || rails4 <= 0 || rails4 >= Rp || (rails4 & 3) || 512L * L.K1 >= (1L << 24)) return FLM_E_ARG;
   if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v | (uintptr_t)target) & 15) return FLM_E_ARG;
-  if (!moments_in != !moments_out || (moments_in && moments_in == moments_out) ||
-      (((uintptr_t)moments_in | (uintptr_t)moments_out) & 7))
+  const bool compact = moments_in != nullptr;
+  if (compact != (moments_out != nullptr) || compact != (m_packed != nullptr) || compact != (v_packed != nullptr) ||
+      (compact && moments_in == moments_out) || (((uintptr_t)moments_in | (uintptr_t)moments_out) & 7))
     return FLM_E_ARG;
   const double bc1 = 1.0 - pow(beta1, (double)step);
   const double bc2 = 1.0 - pow(beta2, (double)step);
@@ -2571,25 +2611,28 @@ extern "C" int flm_dqn_adam_soft_update_rails(float* params, const float* grads,
                      target, n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)(lr / bc1),       \
                      (float)sqrt(bc2), (float)tau, (float)(1.0 - tau), L.a1_w, L.a1_b, L.v1_w, L.v1_b, (unsigned)L.K1,         \
                      (unsigned)(3 * Rp), (unsigned)Rp, (unsigned)rails4, 1.0f / (float)L.K1, 1.0f / (float)(3 * Rp),           \
-                     1.0f / (float)Rp, rcb, reinterpret_cast<const float2*>(moments_in), reinterpret_cast<float2*>(moments_out))
-  if (moments_in) FLM_ADAM_RAILS(true);
+                     1.0f / (float)Rp, rcb, reinterpret_cast<const float2*>(moments_in), reinterpret_cast<float2*>(moments_out), \
+                     m_packed, v_packed)
+  if (compact) FLM_ADAM_RAILS(true);
   else FLM_ADAM_RAILS(false);
 #undef FLM_ADAM_RAILS
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
 }
 
-extern "C" int flm_dqn_adam_moments(float* m, float* v, long n, int Rp, int T1, int NA, int rails4, float* moments, int fill,
-                                    void* stream) {
-  if (!m || !v || !moments || n <= 0 || Rp <= 0 || T1 <= 0 || !actions_ok(NA) || ((uintptr_t)moments & 7)) return FLM_E_ARG;
+extern "C" int flm_dqn_adam_moments(float* m, float* v, long n, int Rp, int T1, int NA, int rails4, float* moments,
+                                    float* m_packed, float* v_packed, int fill, void* stream) {
+  if (!m || !v || !moments || !m_packed || !v_packed || n <= 0 || Rp <= 0 || T1 <= 0 || !actions_ok(NA) ||
+      ((uintptr_t)moments & 7))
+    return FLM_E_ARG;
   const DqnLayout L(3 * Rp, T1, NA);
   if (n != L.total || rails4 <= 0 || rails4 >= Rp) return FLM_E_ARG;
   if (fill)
-    hipLaunchKernelGGL(flm::adam_moments_fill_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, m, v, L.a1_w, L.v1_w, L.K1,
-                       3 * Rp, Rp, rails4, reinterpret_cast<const float2*>(moments));
+    hipLaunchKernelGGL(flm::adam_moments_kernel<true>, dim3(1024), dim3(256), 0, (hipStream_t)stream, m, v, L.a1_w, L.v1_w, L.K1,
+                       3 * Rp, Rp, rails4, reinterpret_cast<float2*>(moments), m_packed, v_packed);
   else
-    hipLaunchKernelGGL(flm::adam_moments_take_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, m, v, L.a1_w, L.v1_w, L.K1,
-                       3 * Rp, rails4, reinterpret_cast<float2*>(moments));
+    hipLaunchKernelGGL(flm::adam_moments_kernel<false>, dim3(1024), dim3(256), 0, (hipStream_t)stream, m, v, L.a1_w, L.v1_w,
+                       L.K1, 3 * Rp, Rp, rails4, reinterpret_cast<float2*>(moments), m_packed, v_packed);
   if (hipGetLastError() != hipSuccess) return FLM_E_LAUNCH;
   return FLM_OK;
 }

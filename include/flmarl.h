@@ -478,24 +478,30 @@ int flm_dqn_learn_grads_u8_rails(const float* local, const float* target, const 
                                  float* workspace, float* grads, float* loss_out, int fill_padding, int phase,
                                  void* stream);
 
-/* fill_padding = 0 (only when flm_dqn_learn_rails(...) > 0): the first dense layer's weight gradient under the empty
- * rows is left unwritten - it is relu(conv bias[c]) times the layer's bias gradient, and flm_dqn_adam_soft_update_rails
+/* fill_padding = 0 or 2 (only when flm_dqn_learn_rails(...) > 0; 2: see the compact form below): the first dense
+ * layer's weight gradient under the empty rows is left unwritten - it is relu(conv bias[c]) times the layer's bias gradient, and flm_dqn_adam_soft_update_rails
  * forms it from the bias gradient in `grads` (after any averaging over ranks) and from the 64 values relu(conv bias)
  * that the learn step left in its workspace at float offset flm_dqn_learn_rails_rcb_offset(...): the same update as
  * flm_dqn_adam_soft_update after a step with fill_padding = 1, without writing and reading those products.
  * rails4 = flm_dqn_learn_rails(...); n = flm_dqn_param_count(3*Rp, T1, NA); 512 * 64 * 3 * Rp < 2^24.
- * moments_in / moments_out (both or neither; two different buffers of 2*512*64 float pairs (m, v), 8-byte aligned): the
- * moments of the weights under the empty rows kept once per (stream, output unit, filter) - they are equal along the
- * rows as long as every step so far gave those weights the same gradient, i.e. every step since m = v = 0 ran over
- * used rails <= rails4.  The pass then reads them from moments_in, writes the new ones to moments_out and leaves m and
- * v under the empty rows untouched (stale); parameters and target get the same bits as without.
- * flm_dqn_adam_moments moves between the two forms: fill = 0 takes the pairs from m and v (at plane 0, rail rails4),
- * fill = 1 writes every m and v under rails >= rails4 from its pair.  The caller keeps track of which form is current. */
+ * The compact form (moments_in, moments_out, m_packed, v_packed: all or none) keeps the optimizer's own data of the two
+ * weight blocks without the empty rows.  moments_in / moments_out: two different buffers of 2*512*64 float pairs (m, v),
+ * 8-byte aligned - the moments of the weights under the empty rows once per (stream, output unit, filter); they are
+ * equal along the rows as long as every step so far gave those weights the same gradient, i.e. every step since
+ * m = v = 0 ran over used rails <= rails4.  m_packed / v_packed [2][512][64*3*rails4]: the moments under the used rails
+ * (column = (filter*3 + plane)*rails4 + rail).  The gradient of the two weight blocks is then read in that packed form
+ * from the start of each block of `grads`, where flm_dqn_learn_grads_u8_rails leaves it with fill_padding = 2.  The pass
+ * reads moments_in, writes moments_out, updates m_packed / v_packed and does not touch m and v of the two weight blocks
+ * (they go stale); parameters and target get the same bits as without.
+ * flm_dqn_adam_moments moves the moments between the two forms: fill = 0 takes pairs and packed moments from m and v
+ * (the pairs at plane 0, rail rails4), fill = 1 writes m and v of the two weight blocks from them.  The caller keeps
+ * track of which form is current. */
 int flm_dqn_adam_soft_update_rails(float* params, const float* grads, float* m, float* v, float* target, long n, double lr,
                                    double beta1, double beta2, double eps, int step, double tau, int Rp, int T1, int NA,
-                                   int rails4, const float* rcb, const float* moments_in, float* moments_out, void* stream);
-int flm_dqn_adam_moments(float* m, float* v, long n, int Rp, int T1, int NA, int rails4, float* moments, int fill,
-                         void* stream);
+                                   int rails4, const float* rcb, const float* moments_in, float* moments_out,
+                                   float* m_packed, float* v_packed, void* stream);
+int flm_dqn_adam_moments(float* m, float* v, long n, int Rp, int T1, int NA, int rails4, float* moments, float* m_packed,
+                         float* v_packed, int fill, void* stream);
 long flm_dqn_learn_rails_rcb_offset(int B, int Rp, int T1, int NA);
 
 /* Uniform sampling without replacement from a replay memory that lives in device memory, and the gather of the

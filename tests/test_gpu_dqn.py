@@ -797,7 +797,7 @@ def test_learn_over_the_used_rails_matches_the_plain_learn_step(Rp, T1, B, rails
             if fused:
                 off = query("flm_dqn_learn_rails_rcb_offset", B, Rp, T1, 2)
                 call("flm_dqn_adam_soft_update_rails", ptr(p_), ptr(gbuf), ptr(m_), ptr(v_), ptr(t_), n, 1e-3, 0.9, 0.999, 1e-8, 3,
-                     0.01, Rp, T1, 2, rails4, ptr(ws[off:off + 64]), None, None, st)
+                     0.01, Rp, T1, 2, rails4, ptr(ws[off:off + 64]), None, None, None, None, st)
             else:
                 assert not torch.isnan(gbuf).any()
                 call("flm_dqn_adam_soft_update", ptr(p_), ptr(gbuf), ptr(m_), ptr(v_), ptr(t_), n, 1e-3, 0.9, 0.999, 1e-8, 3, 0.01, st)
@@ -808,10 +808,63 @@ def test_learn_over_the_used_rails_matches_the_plain_learn_step(Rp, T1, B, rails
         assert not torch.equal(outs[0][0], local)
 
 
-def test_optimizer_with_the_moments_under_the_empty_rows_kept_once_gives_the_same_bits():
-    """FlatAdam keeps the moments of the first dense layer's weights under the empty rows once per (unit, filter) while
-    every step ran over the used rails: parameters and target after several steps (the used rails growing on the way),
-    and the moments once they are read, equal those of the pass that keeps every moment."""
+def _pack_weight_blocks(g, Rp, T1, r4):
+    """The flat gradient with the two weight blocks of the first dense layer in the packed form: [512][64*3*r4] (filter,
+    plane, rail < r4) at the start of each block, the rest of the block never read (NaN)."""
+    K1 = 64 * 3 * Rp
+    a1_w = 64 * T1 + 64
+    out = g.clone()
+    for w in (a1_w, a1_w + 512 * K1 + 512):
+        blk = g[w:w + 512 * K1].view(512, 64, 3, Rp)[:, :, :, :r4].reshape(-1)
+        out[w:w + 512 * K1] = float("nan")
+        out[w:w + blk.numel()] = blk
+    return out
+
+
+def test_learn_step_leaves_the_packed_gradient_the_optimizer_reads():
+    """fill_padding = 2: the two weight blocks' gradient under the used rails, packed at the start of each block, has the
+    bits of the scattered form (fill_padding = 0); everything outside the two blocks is the same."""
+    from flatland_marl_amd._lib import call, ptr, query
+    Rp, T1, B, rails = 70, 151, 64, 17
+    ps = (Rp * T1 + 255) // 256 * 256
+    n = query("flm_dqn_param_count", 3 * Rp, T1, 2)
+    g = torch.Generator().manual_seed(21)
+    local = (torch.randn(n, generator=g) * 0.05).cuda()
+    target = (torch.randn(n, generator=g) * 0.05).cuda()
+    both = torch.zeros((2 * B, 3, ps), dtype=torch.uint8)
+    both[:, :, :rails * T1] = (torch.rand((2 * B, 3, rails * T1), generator=g) < 0.05).to(torch.uint8)
+    both = both.cuda()
+    act = torch.randint(0, 2, (B,), generator=g).cuda()
+    rew, done = torch.randn(B, generator=g).cuda(), (torch.rand(B, generator=g) < 0.2).float().cuda()
+    ws = torch.empty(query("flm_dqn_learn_workspace_u8", B, Rp, T1, 2), device="cuda")
+    r4 = query("flm_dqn_learn_rails", B, Rp, T1, rails)
+    assert r4 == 20
+    outs = []
+    for fill in (0, 2):
+        gbuf, loss = torch.full((n,), float("nan"), device="cuda"), torch.zeros(1, device="cuda")
+        call("flm_dqn_learn_grads_u8_rails", ptr(local), ptr(target), ptr(both[:B]), ptr(both[B:]), ps, ptr(act), ptr(rew),
+             ptr(done), 0.97, 1, B, Rp, T1, 2, rails, ptr(ws), ptr(gbuf), ptr(loss), fill, 0, 0)
+        torch.cuda.synchronize()
+        outs.append((gbuf, loss))
+    want = _pack_weight_blocks(outs[0][0], Rp, T1, r4)
+    got = outs[1][0]
+    K1, Kc = 64 * 3 * Rp, 64 * 3 * r4
+    a1_w = 64 * T1 + 64
+    for w in (a1_w, a1_w + 512 * K1 + 512):
+        assert torch.equal(got[w:w + 512 * Kc], want[w:w + 512 * Kc]) and not torch.isnan(got[w:w + 512 * Kc]).any()
+        assert got[w:w + 512 * Kc].abs().max() > 0
+        got[w:w + 512 * K1] = 0
+        want[w:w + 512 * K1] = 0
+    assert torch.equal(got, want) and torch.equal(outs[0][1], outs[1][1])
+    with pytest.raises(Exception):                      # a batch too small for the used-rails form has no packed form
+        call("flm_dqn_learn_grads_u8_rails", ptr(local), ptr(target), ptr(both[:4]), ptr(both[B:B + 4]), ps, ptr(act), ptr(rew),
+             ptr(done), 0.97, 1, 4, Rp, T1, 2, rails, ptr(ws), ptr(outs[0][0]), ptr(outs[0][1]), 2, 0, 0)
+
+
+def test_optimizer_in_the_compact_form_gives_the_same_bits():
+    """FlatAdam keeps its data of the first dense layer's weights without the empty rows while every step ran over the
+    used rails: parameters and target after several steps (the used rails growing on the way), and the moments once
+    they are read, equal those of the pass that keeps every moment."""
     from flatland_marl_amd._lib import call, ptr, query
     from flatland_marl_amd.agent import FlatAdam
     from flatland_marl_amd.model import Dueling_DQN
@@ -838,15 +891,15 @@ def test_optimizer_with_the_moments_under_the_empty_rows_kept_once_gives_the_sam
         rcb = torch.rand(64, generator=gen).cuda()
         rcb[::5] = 0.0
         call("flm_dqn_adam_soft_update_rails", ptr(p_e), ptr(g), ptr(m_e), ptr(v_e), ptr(t_e), n, 1e-3, 0.9, 0.999, 1e-8, step,
-             0.01, Rp, T1, NA, r4, ptr(rcb), None, None, 0)
-        opt.grads.copy_(g)
-        opt.step(target=t_c, tau=0.01, rails=(Rp, T1, NA, r4, rcb))
+             0.01, Rp, T1, NA, r4, ptr(rcb), None, None, None, None, 0)
+        assert opt.compact_for(Rp, T1, NA, r4)
+        opt.grads.copy_(_pack_weight_blocks(g, Rp, T1, r4))
+        opt.step(target=t_c, tau=0.01, rails=(Rp, T1, NA, r4, rcb, True))
         forms.append(opt._compact)
         torch.cuda.synchronize()
         assert torch.equal(flat, p_e) and torch.equal(t_c, t_e), step
     assert forms == [(Rp, T1, NA, 20)] * 2 + [(Rp, T1, NA, 24)] * 3 + [(Rp, T1, NA, 32)]
-    stale = not torch.equal(opt._m, m_e)
-    assert stale                                                  # the large buffers were indeed left behind
+    assert not torch.equal(opt._m, m_e)                           # the large buffers were indeed left behind
     assert torch.equal(opt.m, m_e) and torch.equal(opt.v, v_e)    # reading them brings them up to date
     assert opt._compact is None and opt._uniform_from is None
     assert not torch.isnan(m_e).any() and not torch.isnan(p_e).any()
@@ -854,9 +907,13 @@ def test_optimizer_with_the_moments_under_the_empty_rows_kept_once_gives_the_sam
     g = torch.randn(n, generator=gen).cuda() * 0.1
     rcb = torch.rand(64, generator=gen).cuda()
     call("flm_dqn_adam_soft_update_rails", ptr(p_e), ptr(g), ptr(m_e), ptr(v_e), ptr(t_e), n, 1e-3, 0.9, 0.999, 1e-8, 7, 0.01,
-         Rp, T1, NA, 32, ptr(rcb), None, None, 0)
+         Rp, T1, NA, 32, ptr(rcb), None, None, None, None, 0)
+    assert not opt.compact_for(Rp, T1, NA, 32)
+    with pytest.raises(ValueError):
+        opt.step(target=t_c, tau=0.01, rails=(Rp, T1, NA, 32, rcb, True))
+    opt.step_count -= 1
     opt.grads.copy_(g)
-    opt.step(target=t_c, tau=0.01, rails=(Rp, T1, NA, 32, rcb))
+    opt.step(target=t_c, tau=0.01, rails=(Rp, T1, NA, 32, rcb, False))
     assert opt._compact is None
     call("flm_dqn_adam_soft_update", ptr(p_e), ptr(g), ptr(m_e), ptr(v_e), ptr(t_e), n, 1e-3, 0.9, 0.999, 1e-8, 8, 0.01, 0)
     opt.step(target=t_c, tau=0.01)
@@ -865,7 +922,7 @@ def test_optimizer_with_the_moments_under_the_empty_rows_kept_once_gives_the_sam
 
 
 def test_a_plain_step_after_steps_over_the_used_rails_finds_every_moment():
-    """A step that is not over the used rails (here: the float learn path's) first spreads the moments kept once."""
+    """A step that is not over the used rails (here: the float learn path's) first spreads the compact moments."""
     from flatland_marl_amd._lib import call, ptr
     from flatland_marl_amd.agent import FlatAdam
     from flatland_marl_amd.model import Dueling_DQN
@@ -884,12 +941,13 @@ def test_a_plain_step_after_steps_over_the_used_rails_finds_every_moment():
         rcb = torch.rand(64, generator=gen).cuda()
         if step < 3:
             call("flm_dqn_adam_soft_update_rails", ptr(p_e), ptr(g), ptr(m_e), ptr(v_e), ptr(t_e), n, 1e-3, 0.9, 0.999, 1e-8,
-                 step, 0.01, Rp, T1, NA, 12, ptr(rcb), None, None, 0)
+                 step, 0.01, Rp, T1, NA, 12, ptr(rcb), None, None, None, None, 0)
+            opt.grads.copy_(_pack_weight_blocks(g, Rp, T1, 12))
         else:
             call("flm_dqn_adam_soft_update", ptr(p_e), ptr(g), ptr(m_e), ptr(v_e), ptr(t_e), n, 1e-3, 0.9, 0.999, 1e-8, step,
                  0.01, 0)
-        opt.grads.copy_(g)
-        opt.step(target=t_c, tau=0.01, rails=(Rp, T1, NA, 12, rcb) if step < 3 else None)
+            opt.grads.copy_(g)
+        opt.step(target=t_c, tau=0.01, rails=(Rp, T1, NA, 12, rcb, True) if step < 3 else None)
         assert (opt._compact is not None) == (step < 3)
     torch.cuda.synchronize()
     assert torch.equal(flat, p_e) and torch.equal(t_c, t_e) and torch.equal(opt._m, m_e) and torch.equal(opt._v, v_e)

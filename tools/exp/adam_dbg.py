@@ -22,7 +22,7 @@ for Rp, T1, r4 in ((70, 151, 20), (100, 151, 24)):
         m = torch.randn(n, generator=torch.Generator().manual_seed(3)).cuda() * 1e-3
         v = torch.rand(n, generator=torch.Generator().manual_seed(4)).cuda() * 1e-6
         if fused:
-            call("flm_dqn_adam_soft_update_rails", ptr(p), ptr(part), ptr(m), ptr(v), ptr(t), n, 1e-3, 0.9, 0.999, 1e-8, 3, 0.01, Rp, T1, 2, r4, ptr(rcb), None, None, 0)
+            call("flm_dqn_adam_soft_update_rails", ptr(p), ptr(part), ptr(m), ptr(v), ptr(t), n, 1e-3, 0.9, 0.999, 1e-8, 3, 0.01, Rp, T1, 2, r4, ptr(rcb), None, None, None, None, 0)
         else:
             call("flm_dqn_adam_soft_update", ptr(p), ptr(full), ptr(m), ptr(v), ptr(t), n, 1e-3, 0.9, 0.999, 1e-8, 3, 0.01, 0)
         torch.cuda.synchronize()

@@ -16,7 +16,8 @@ def timed(f, reps=30):
     torch.cuda.synchronize()
     return float(np.median([x.elapsed_time(y) for x, y in ev])) * 1e3
 print("plain  %.1f us" % timed(lambda: call("flm_dqn_adam_soft_update", ptr(p), ptr(g), ptr(m), ptr(v), ptr(t), n, 1e-3, 0.9, 0.999, 1e-8, 3, 0.01, 0)))
-print("rails  %.1f us" % timed(lambda: call("flm_dqn_adam_soft_update_rails", ptr(p), ptr(g), ptr(m), ptr(v), ptr(t), n, 1e-3, 0.9, 0.999, 1e-8, 3, 0.01, Rp, T1, 2, r4, ptr(rcb), None, None, 0)))
-print("compact %.1f us" % timed(lambda: call("flm_dqn_adam_soft_update_rails", ptr(p), ptr(g), ptr(m), ptr(v), ptr(t), n, 1e-3, 0.9, 0.999, 1e-8, 3, 0.01, Rp, T1, 2, r4, ptr(rcb), ptr(pa[0]), ptr(pa[1]), 0)))
+print("rails  %.1f us" % timed(lambda: call("flm_dqn_adam_soft_update_rails", ptr(p), ptr(g), ptr(m), ptr(v), ptr(t), n, 1e-3, 0.9, 0.999, 1e-8, 3, 0.01, Rp, T1, 2, r4, ptr(rcb), None, None, None, None, 0)))
+mpk, vpk = (torch.rand(2 * 512 * 64 * 3 * r4, device="cuda") for _ in range(2))
+print("compact %.1f us" % timed(lambda: call("flm_dqn_adam_soft_update_rails", ptr(p), ptr(g), ptr(m), ptr(v), ptr(t), n, 1e-3, 0.9, 0.999, 1e-8, 3, 0.01, Rp, T1, 2, r4, ptr(rcb), ptr(pa[0]), ptr(pa[1]), ptr(mpk), ptr(vpk), 0)))
 print("copy p->t (2x55MB) %.1f us" % timed(lambda: t.copy_(p)))
 print("memset %.1f us" % timed(lambda: t.zero_()))
