@@ -200,7 +200,9 @@ class DQNAgent:
         """learn() on uint8 observations [B,3,plane_stride] (plane 0 int8, heat planes uint8) as a device replay
         memory stores them: same update, no float copies of the next states.  rails_used > 0: the caller vouches that
         rails rails_used.. of every plane of every observation are empty (the padding up to max_rails); the step
-        then computes over the used rails and adds what the empty ones contribute in closed form."""
+        then computes over the used rails and adds what the empty ones contribute in closed form.  With several ranks
+        every rank must pass the same rails_used (the largest of theirs): the ranks' gradients are added element by
+        element, and what one rank leaves to the closed form another must not have computed from data."""
         states, actions, rewards, next_states, dones = experiences
         B = states.size(0)
         if self.height % 3:
@@ -230,7 +232,8 @@ class DQNAgent:
         args = (ptr(local), ptr(target), ptr(s), ptr(sn), int(plane_stride), ptr(a), ptr(r), ptr(d),
                 float(gamma), 1 if self.double_dqn else 0, B, Rp, self.width, self.action_space, int(rails_used),
                 ptr(self._ws), ptr(self.optimizer.grads), ptr(loss), (2 if packed else 0) if fused else 1)
-        self._grads_and_exchange("flm_dqn_learn_grads_u8_rails", args, st, phased_entry=True)
+        self._grads_and_exchange("flm_dqn_learn_grads_u8_rails", args, st, phased_entry=True,
+                                 packed_cols=64 * 3 * rails4 if packed else 0)
         self.last_loss = loss
         if fused:
             off = query("flm_dqn_learn_rails_rcb_offset", B, Rp, self.width, self.action_space)
@@ -239,12 +242,14 @@ class DQNAgent:
         else:
             self._update(target)
 
-    def _grads_and_exchange(self, entry, args, stream, phased_entry=False):
+    def _grads_and_exchange(self, entry, args, stream, phased_entry=False, packed_cols=0):
         """The gradients of one learn step and, with several ranks, their average over the ranks (the reference is a
         single process, src/agent.py:14: one rank is its algorithm).  Data parallel: the step runs in two halves;
         the gradients of the dense layers (98 % of the flat buffer) are final after the first and travel while the
         second computes the convolution's, whose small sum follows; both are waited for before the optimizer.
-        phased_entry: the entry point itself takes the phase (0 = the whole step) in front of the stream."""
+        phased_entry: the entry point itself takes the phase (0 = the whole step) in front of the stream.
+        packed_cols > 0: the two weight blocks of the first dense layer hold [512, packed_cols] gradients at their
+        start and nothing behind them (fill_padding = 2): only what is there travels."""
         whole = (lambda: call(entry, *args, 0, stream)) if phased_entry else (lambda: call(entry, *args, stream))
         half = (lambda ph: call(entry, *args, ph, stream)) if phased_entry else (lambda ph: call(entry + "_phase", *args, ph, stream))
         if not parallel.distributed():
@@ -254,7 +259,15 @@ class DQNAgent:
         split = query("flm_dqn_grad_split", self.height, self.width, self.action_space)
         ex = self.exchange = parallel.GradientExchange()
         half(1)
-        ex.begin(grads[split:])
+        if packed_cols:
+            a1_w, block = split, 512 * 64 * self.height          # flat layout: weights [512, 64*height], then 512 biases
+            a1_b = a1_w + block
+            v1_w = a1_b + 512
+            ex.begin(grads[a1_w:a1_w + 512 * packed_cols])       # advantage stream's packed weights
+            ex.begin(grads[a1_b:v1_w + 512 * packed_cols])       # its biases and the value stream's packed weights
+            ex.begin(grads[v1_w + block:])                       # the value stream's biases and the output layers
+        else:
+            ex.begin(grads[split:])
         half(2)
         ex.begin(grads[:split])
         ex.finish()

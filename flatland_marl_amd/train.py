@@ -171,12 +171,15 @@ class BatchedTrainer:
         self.t_step = 0
         self.n_learn = 0
         self.n_transitions = 0
+        self._rails_seen = 0
 
     def _learn(self):
         b = self.ro.b
         # every observation in the memory comes from this batch of environments: rails beyond its largest count are
         # empty, neither gathered nor computed
-        rails = self._rails_seen = max(getattr(self, "_rails_seen", 0), self.ro.rails_used())   # of anything ever stored
+        # (of anything ever stored; with several ranks the largest over the ranks, agreed on in step(): the ranks' learn
+        # steps must leave the same rows to the closed forms, or their gradients do not add up)
+        rails = self._rails_seen = max(self._rails_seen, self.ro.rails_used())
         used = query("flm_dqn_learn_rails", self.agent.args.batch_size, b.Rp, b.T1, rails) * b.T1
         self.agent.learn_obs(self.replay.sample(self.agent.args.batch_size, used_bytes=used), self.agent.args.gamma,
                              b.plane_stride, rails_used=rails)
@@ -212,6 +215,8 @@ class BatchedTrainer:
                 due = 0
             # data parallel: every learn step all-reduces the gradient, so all ranks take the same number
             due = parallel.min_over_ranks(due, ro.device)
+            if parallel.distributed():
+                self._rails_seen = int(parallel.max_over_ranks(max(self._rails_seen, ro.rails_used()), ro.device))
             for _ in range(due):
                 self._learn()
         return n_new
