@@ -682,14 +682,25 @@ __global__ __launch_bounds__(64) void head_forward_kernel(const float* __restric
 // sample: bias2[o] = bias[o] + sum over filters c of relu(conv_b[c]) * wpad[o][c], where wpad[o][c] is the sum of
 // W[o][c*H3 + plane*Rp + rail] over the planes and the rails >= R4.  One workgroup per output unit o (advantage stream
 // first); all sums in a fixed order.  wpad_out (optional): wpad as [64][1024] (filter-major), which the backward pass needs as well.
-__global__ __launch_bounds__(256) void fc1_padding_bias_kernel(const float* __restrict__ Wa, const float* __restrict__ Wv,
-                                                               const float* __restrict__ bias_a, const float* __restrict__ bias_v,
-                                                               const float* __restrict__ conv_b, long K1, int H3, int Rp, int R4,
-                                                               float* __restrict__ bias2, float* __restrict__ wpad_out,
-                                                               float* __restrict__ rcb_out) {
+// (workgroups 1024.. do the same for a second network, j1: a learn step needs both networks' vectors)
+struct PaddingBiasJob {
+  const float *Wa, *Wv, *bias_a, *bias_v, *conv_b;
+  float *bias2, *wpad_out, *rcb_out;
+};
+__global__ __launch_bounds__(256) void fc1_padding_bias_kernel(PaddingBiasJob j0, PaddingBiasJob j1, long K1, int H3, int Rp,
+                                                               int R4) {
   __shared__ float lane_sum[64][65];
   __shared__ float red[64];
-  const int o = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const PaddingBiasJob& j = blockIdx.x >= 1024 ? j1 : j0;
+  const float* __restrict__ Wa = j.Wa;
+  const float* __restrict__ Wv = j.Wv;
+  const float* __restrict__ bias_a = j.bias_a;
+  const float* __restrict__ bias_v = j.bias_v;
+  const float* __restrict__ conv_b = j.conv_b;
+  float* __restrict__ bias2 = j.bias2;
+  float* __restrict__ wpad_out = j.wpad_out;
+  float* __restrict__ rcb_out = j.rcb_out;
+  const int o = blockIdx.x & 1023, t = threadIdx.x, lane = t & 63, w = t >> 6;
   const float* W = o < 512 ? Wa + (long)o * K1 : Wv + (long)(o - 512) * K1;
   const int L = Rp - R4;
   // a wave takes every fourth filter, its lanes the consecutive weights of a segment: 48 independent loads per lane
@@ -2136,14 +2147,22 @@ static int dqn_rails_used(int B, int Rp, int rails_used) {
 // bias2: 1024 floats of workspace.
 // The dense layers behind a convolution over the used rails: x1c [B,64,3*R4] -> hid, q.  bias2: 1024 floats of
 // workspace; wpad_out: 1024*64 floats or nullptr (fc1_padding_bias_kernel).
+static flm::PaddingBiasJob padding_bias_job(const float* params, const DqnLayout& L, float* bias2, float* wpad_out,
+                                            float* rcb_out) {
+  return flm::PaddingBiasJob{params + L.a1_w, params + L.v1_w, params + L.a1_b, params + L.v1_b, params + L.conv_b,
+                             bias2, wpad_out, rcb_out};
+}
+
 static int dqn_dense_stage_rails(const float* params, int B, int Rp, int R4, int T1, int NA, const float* x1c, float* hid,
                                  float* part, float* bias2, float* wpad_out, float* q, hipStream_t stream,
-                                 float* rcb_out = nullptr) {
+                                 float* rcb_out = nullptr, bool bias2_ready = false) {
   const int H3 = 3 * Rp;
   DqnLayout L(H3, T1, NA);
   int rc;
-  hipLaunchKernelGGL(flm::fc1_padding_bias_kernel, dim3(1024), dim3(256), 0, stream, params + L.a1_w, params + L.v1_w,
-                     params + L.a1_b, params + L.v1_b, params + L.conv_b, L.K1, H3, Rp, R4, bias2, wpad_out, rcb_out);
+  if (!bias2_ready) {
+    const flm::PaddingBiasJob j = padding_bias_job(params, L, bias2, wpad_out, rcb_out);
+    hipLaunchKernelGGL(flm::fc1_padding_bias_kernel, dim3(1024), dim3(256), 0, stream, j, j, L.K1, H3, Rp, R4);
+  }
   const long Kc = 192L * R4;
   const int nks = fc1_k_slices(B, Kc);
   const int ks = (int)(((Kc + nks - 1) / nks + XBK - 1) / XBK * XBK);
@@ -2323,10 +2342,16 @@ static int learn_dense_half(const float* local, const float* target, const float
   }
   const int n_local = double_dqn ? 2 * B : B;
   if (R4) {
-    if ((rc = dqn_dense_stage_rails(local, n_local, Rp, R4, T1, NA, w.x1, w.hid, w.part, w.bias2, w.wpad, w.q, stream, w.rcb)))
+    // the padding's share of the bias for both networks: one launch
+    hipLaunchKernelGGL(flm::fc1_padding_bias_kernel, dim3(2048), dim3(256), 0, stream,
+                       padding_bias_job(local, L, w.bias2, w.wpad, w.rcb),
+                       padding_bias_job(target, L, w.bias2 + 1024, nullptr, nullptr), L.K1, H3, Rp, R4);
+    if ((rc = dqn_dense_stage_rails(local, n_local, Rp, R4, T1, NA, w.x1, w.hid, w.part, w.bias2, w.wpad, w.q, stream, w.rcb,
+                                    true)))
       return rc;
     if (!target_conv_done && (rc = dqn_conv_stage(target, nullptr, sn_u8, plane_stride, B, H3c, T1, NA, w.x1t, stream))) return rc;
-    rc = dqn_dense_stage_rails(target, B, Rp, R4, T1, NA, w.x1t, w.hidt, w.part, w.bias2 + 1024, nullptr, w.qt, stream);
+    rc = dqn_dense_stage_rails(target, B, Rp, R4, T1, NA, w.x1t, w.hidt, w.part, w.bias2 + 1024, nullptr, w.qt, stream, nullptr,
+                               true);
   } else {
     if ((rc = dqn_dense_stage(local, n_local, H3, T1, NA, w.x1, w.hid, w.part, w.q, stream))) return rc;
     if (target_conv_done)

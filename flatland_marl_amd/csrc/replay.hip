@@ -107,6 +107,8 @@ __global__ __launch_bounds__(256) void replay_gather_planes_kernel(const uint8_t
 // same few dozen integer operations, on values that are the same for the whole workgroup), so the list of indices
 // never has to reach memory before the rows are fetched; it is still written, for callers that want it.
 // used_bytes == plane_bytes and n_planes * plane_bytes == row_bytes copies whole rows.
+// (pieces of 4 KiB: one 16-byte copy per thread and field, so that a few hundred rows still fill the chip)
+constexpr unsigned DRAW_GATHER_PIECE = 4096;
 __global__ __launch_bounds__(256) void replay_draw_gather_kernel(
     const uint8_t* __restrict__ state, const uint8_t* __restrict__ next_state, const int64_t* __restrict__ action,
     const float* __restrict__ reward, const float* __restrict__ done, int size, uint32_t seed, uint32_t draw, long row_bytes,
@@ -117,8 +119,8 @@ __global__ __launch_bounds__(256) void replay_draw_gather_kernel(
   const int32_t x = replay_sampled_index(size, seed, draw, b);
   const long src = (long)x * row_bytes, dst = (long)b * row_bytes;
   const unsigned total = used_bytes * n_planes;
-  const unsigned lo = blockIdx.x * 16384u;
-  const unsigned hi = lo + 16384u < total ? lo + 16384u : total;
+  const unsigned lo = blockIdx.x * DRAW_GATHER_PIECE;
+  const unsigned hi = lo + DRAW_GATHER_PIECE < total ? lo + DRAW_GATHER_PIECE : total;
   for (unsigned o = lo + threadIdx.x * 16u; o < hi; o += 256u * 16u) {
     const unsigned pl = o / used_bytes;
     const long at = (long)pl * plane_bytes + (o - pl * used_bytes);
@@ -491,7 +493,7 @@ extern "C" int flm_replay_draw_gather(const void* state, const void* next_state,
       (used_bytes & 15) || used_bytes > plane_bytes || (long)n_planes * plane_bytes > row_bytes || row_bytes >= (1L << 31))
     return FLM_E_ARG;
   if (((uintptr_t)state | (uintptr_t)next_state | (uintptr_t)out_state | (uintptr_t)out_next) & 15) return FLM_E_ARG;
-  dim3 grid((unsigned)((used_bytes * n_planes + 16383) / 16384), (unsigned)batch);
+  dim3 grid((unsigned)((used_bytes * n_planes + flm::DRAW_GATHER_PIECE - 1) / flm::DRAW_GATHER_PIECE), (unsigned)batch);
   hipLaunchKernelGGL(flm::replay_draw_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)state,
                      (const uint8_t*)next_state, action, reward, done, size, seed, draw, row_bytes, (unsigned)n_planes,
                      (unsigned)plane_bytes, (unsigned)used_bytes, (uint8_t*)out_state, (uint8_t*)out_next, out_action,
