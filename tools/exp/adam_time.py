@@ -1,3 +1,5 @@
+"""Times of the optimizer pass in its three forms (every moment; gradient under the empty rows formed in the pass; compact
+form with packed moments and gradient) beside a plain copy and a memset of the same buffers (development tool)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
