@@ -79,6 +79,33 @@ def test_training_episode_runs_and_learns():
     assert out2["steps"] >= 1 and out2["eps"] < 0.5
 
 
+def test_training_with_the_optimizer_in_its_compact_form_gives_the_same_weights():
+    """The trainer's learn steps run over the used rails with the optimizer's data of the first dense layer kept
+    without the empty rows (packed gradient, packed moments, one pair of moments per unit and filter for the rows that
+    are empty).  The same episode with that form switched off (every moment kept, gradient scattered into the flat
+    layout) must leave the same parameters, target parameters and moments, bit for bit."""
+    import torch
+    out = []
+    for compact in (True, False):
+        ro, agent, tr = _setup(E=6, A=8, depth=40, Rp=40, max_learns_per_step=3, start_eps=0.3, max_steps=30, seed=3)
+        agent.args.lr = 1e-3
+        agent.optimizer.lr = 1e-3
+        if not compact:
+            agent.optimizer._ensure()
+            agent.optimizer._uniform_from = None               # as after any step of another kind: the form is never taken
+        summary = tr.run_episode(train=True)
+        torch.cuda.synchronize()
+        assert summary["learns"] >= 10
+        used_form = agent.optimizer._compact is not None
+        assert used_form == compact
+        out.append((agent.qnetwork_local.flat_params().clone(), agent.qnetwork_target.flat_params().clone(),
+                    agent.optimizer.m.clone(), agent.optimizer.v.clone(), summary["learns"], summary["transitions"]))
+    assert out[0][4:] == out[1][4:]
+    for x, y in zip(out[0][:4], out[1][:4]):
+        assert torch.equal(x, y)
+    assert out[0][2].abs().max() > 0
+
+
 def _hash(t):
     import hashlib
     return hashlib.sha1(t.contiguous().cpu().numpy().tobytes()).hexdigest()[:16]
