@@ -951,3 +951,51 @@ def test_a_plain_step_after_steps_over_the_used_rails_finds_every_moment():
         assert (opt._compact is not None) == (step < 3)
     torch.cuda.synchronize()
     assert torch.equal(flat, p_e) and torch.equal(t_c, t_e) and torch.equal(opt._m, m_e) and torch.equal(opt._v, v_e)
+
+
+def test_moments_round_trip_and_argument_checks_of_the_compact_form():
+    """flm_dqn_adam_moments: taking the compact form from m and v and writing it back restores them bit for bit when the
+    moments are equal along the empty rows; the entry points refuse pointer sets that are not all-or-none, the same
+    buffer for moments_in and moments_out, and sizes that do not match the network."""
+    from flatland_marl_amd._lib import FlmError, call, ptr, query
+    Rp, T1, NA, r4 = 23, 31, 3, 8
+    n = query("flm_dqn_param_count", 3 * Rp, T1, NA)
+    K1 = 64 * 3 * Rp
+    a1_w = 64 * T1 + 64
+    v1_w = a1_w + 512 * K1 + 512
+    g = torch.Generator().manual_seed(31)
+    m, v = torch.randn(n, generator=g).cuda(), torch.rand(n, generator=g).cuda()
+    for t in (m, v):                                             # equal along the empty rows of every (unit, filter)
+        for w in (a1_w, v1_w):
+            blk = t[w:w + 512 * K1].view(512, 64, 3, Rp)
+            blk[:, :, :, r4:] = blk[:, :, 0:1, r4:r4 + 1]
+    m0, v0 = m.clone(), v.clone()
+    pairs = torch.empty((2 * 512 * 64, 2), device="cuda")
+    mpk, vpk = (torch.empty(2 * 512 * 64 * 3 * r4, device="cuda") for _ in range(2))
+    call("flm_dqn_adam_moments", ptr(m), ptr(v), n, Rp, T1, NA, r4, ptr(pairs), ptr(mpk), ptr(vpk), 0, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(m, m0) and torch.equal(v, v0)             # taking leaves m and v alone
+    want = m0[a1_w:a1_w + 512 * K1].view(512, 64, 3, Rp)[:, :, :, :r4].reshape(-1)
+    assert torch.equal(mpk[:want.numel()], want)
+    assert torch.equal(pairs[:512 * 64, 1], v0[a1_w:a1_w + 512 * K1].view(512, 64, 3, Rp)[:, :, 0, r4].reshape(-1))
+    for w in (a1_w, v1_w):                                       # what is stale while the compact form is current
+        m[w:w + 512 * K1] = float("nan")
+        v[w:w + 512 * K1] = float("nan")
+    call("flm_dqn_adam_moments", ptr(m), ptr(v), n, Rp, T1, NA, r4, ptr(pairs), ptr(mpk), ptr(vpk), 1, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(m, m0) and torch.equal(v, v0)
+    p, t, gr, rcb = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(64, device="cuda")
+    pairs2 = torch.empty_like(pairs)
+    head = (ptr(p), ptr(gr), ptr(m), ptr(v), ptr(t), n, 1e-3, 0.9, 0.999, 1e-8, 1, 0.01, Rp, T1, NA, r4, ptr(rcb))
+    for extra in ((ptr(pairs), None, ptr(mpk), ptr(vpk)), (ptr(pairs), ptr(pairs2), None, ptr(vpk)),
+                  (ptr(pairs), ptr(pairs), ptr(mpk), ptr(vpk)), (None, ptr(pairs2), None, None)):
+        with pytest.raises(FlmError):
+            call("flm_dqn_adam_soft_update_rails", *head, *extra, 0)
+    with pytest.raises(FlmError):                                # rails4 must be a multiple of four below max_rails
+        call("flm_dqn_adam_soft_update_rails", *head[:15], 6, ptr(rcb), None, None, None, None, 0)
+    with pytest.raises(FlmError):                                # n of another network
+        call("flm_dqn_adam_soft_update_rails", *head[:5], n - 1, *head[6:], None, None, None, None, 0)
+    with pytest.raises(FlmError):
+        call("flm_dqn_adam_moments", ptr(m), ptr(v), n, Rp, T1, NA, Rp, ptr(pairs), ptr(mpk), ptr(vpk), 0, 0)
+    call("flm_dqn_adam_soft_update_rails", *head, ptr(pairs), ptr(pairs2), ptr(mpk), ptr(vpk), 0)   # and a well-formed call passes
+    torch.cuda.synchronize()

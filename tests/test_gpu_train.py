@@ -494,6 +494,16 @@ def test_replay_sampling_kernel():
          ptr(di), B, rp.row_bytes, 3, 48, 32, ptr(o[0]), ptr(o[3]), ptr(o[1]), ptr(o[2]), ptr(o[4]), 0)
     torch.cuda.synchronize()
     assert torch.equal(o[0], s2) and torch.equal(o[3], sn2) and torch.equal(o[1], ac2)
+    # the one-launch form refuses what the two-launch forms refuse
+    from flatland_marl_amd._lib import FlmError
+    base = (ptr(rp.state), ptr(rp.next_state), ptr(rp.action), ptr(rp.reward), ptr(rp.done))
+    outs = (ptr(o[0]), ptr(o[3]), ptr(o[1]), ptr(o[2]), ptr(o[4]), ptr(di))
+    for bad in ((n, 11, 7, n + 1, rp.row_bytes, 1, rp.row_bytes, rp.row_bytes),      # a batch larger than the memory
+                (n, 11, 7, B, rp.row_bytes, 3, 48, 40),                              # used bytes not a multiple of 16
+                (n, 11, 7, B, rp.row_bytes, 4, 48, 32),                              # planes beyond the row
+                (0, 11, 7, B, rp.row_bytes, 3, 48, 32)):                             # an empty memory
+        with pytest.raises(FlmError):
+            call("flm_replay_draw_gather", *base, *bad, *outs, 0)
     # the whole memory can be asked for; more than it holds cannot
     assert sorted(rp.sample_indices(n).cpu().tolist()) == list(range(n))
     with pytest.raises(ValueError):
