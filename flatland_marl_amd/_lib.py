@@ -41,6 +41,7 @@ _SIGNATURES = {
     "flm_observations_req": [_p, _p, _p, _i, _i, _i, _i, _p, _p],
     "flm_reorder_rails": [_p, _p, _i, _i, _i, _i, _p, _p],
     "flm_observations_req_columns": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
+    "flm_observations_req_columns_counted": [_p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p],
     "flm_rollout_requests": [_p] * 5 + [_i, _i] + [_p] * 11,
     "flm_rollout_alt_finish": [_p] * 4 + [_i, _i, _p, _i] + [_p] * 6,
     "flm_policy_select": [_p, _p, _i, _p, _i, _p, _p, C.c_double, _u32, _i, _p, _p, _p, _p, _p],
@@ -48,6 +49,8 @@ _SIGNATURES = {
     "flm_rollout_apply": [_p] * 18 + [_i] * 6 + [_p, _p, _p, _p],
     "flm_env_step": [_p] * 13 + [_i] * 4 + [_p] * 6 + [_u32, _i, _i, _i, _p],
     "flm_altpaths": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
+    "flm_altpaths_counted": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i,
+                             _p, _p, _p, _p, _p, _p],
     "flm_check_crash": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     "flm_update_bitmaps": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "flm_dqn_param_count": [_i, _i, _i],

@@ -449,9 +449,12 @@ __global__ __launch_bounds__(256) void observations_req_columns_kernel(const int
                                                                        const int32_t* __restrict__ own_row, int A, int T1,
                                                                        int plane_stride, int tile_bytes,
                                                                        const int32_t* __restrict__ out_row,
-                                                                       uint8_t* __restrict__ out) {
+                                                                       uint8_t* __restrict__ out,
+                                                                       const int32_t* __restrict__ n_live) {
   extern __shared__ __attribute__((aligned(16))) unsigned req_tile[];   // [3][tile_bytes/4]: own plane, positive heat, negative heat (packed bytes)
   const int g = blockIdx.y, tid = threadIdx.x;
+  // n_live (optional): the launch was sized by an upper bound; the kernel that counted the requests left their number there
+  if (n_live && g >= *n_live) return;
   // out_row (optional): the row of `out` that request g writes (negative: the request is skipped), else row g
   const int dst_row = out_row ? out_row[g] : g;
   if (dst_row < 0) return;
@@ -730,9 +733,9 @@ extern "C" int flm_observations_req(const int8_t* maps, const int32_t* req_agent
   return FLM_OK;
 }
 
-extern "C" int flm_observations_req_columns(const int16_t* cols, const int32_t* req_agent, const int16_t* own_cols,
-                                            const int32_t* own_row, int n_req, int E, int A, int Rp, int T1,
-                                            int plane_stride, uint8_t* out, void* stream) {
+static int observations_req_columns_impl(const int16_t* cols, const int32_t* req_agent, const int16_t* own_cols,
+                                         const int32_t* own_row, int n_req, const int32_t* n_live, int E, int A, int Rp,
+                                         int T1, int plane_stride, uint8_t* out, void* stream) {
   if (!cols || !req_agent || !out) return FLM_E_ARG;
   if (n_req <= 0 || n_req > 65535 || E <= 0 || A <= 0 || A > 255 || Rp <= 0 || T1 <= 0 || plane_stride % 16 != 0 ||
       (long long)plane_stride < (long long)Rp * T1)
@@ -740,9 +743,24 @@ extern "C" int flm_observations_req_columns(const int16_t* cols, const int32_t* 
   const int tile = plane_stride < FLM_REQ_TILE ? plane_stride : FLM_REQ_TILE;      // a multiple of 16
   dim3 grid((plane_stride + tile - 1) / tile, n_req);
   hipLaunchKernelGGL(flm::observations_req_columns_kernel, grid, dim3(256), 3 * (size_t)tile, (hipStream_t)stream, cols,
-                     req_agent, own_cols, own_row, A, T1, plane_stride, tile, nullptr, out);
+                     req_agent, own_cols, own_row, A, T1, plane_stride, tile, nullptr, out, n_live);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
+}
+
+extern "C" int flm_observations_req_columns(const int16_t* cols, const int32_t* req_agent, const int16_t* own_cols,
+                                            const int32_t* own_row, int n_req, int E, int A, int Rp, int T1,
+                                            int plane_stride, uint8_t* out, void* stream) {
+  return observations_req_columns_impl(cols, req_agent, own_cols, own_row, n_req, nullptr, E, A, Rp, T1, plane_stride, out,
+                                       stream);
+}
+
+extern "C" int flm_observations_req_columns_counted(const int16_t* cols, const int32_t* req_agent, const int16_t* own_cols,
+                                                    const int32_t* own_row, int n_max, const int32_t* n_live, int E, int A,
+                                                    int Rp, int T1, int plane_stride, uint8_t* out, void* stream) {
+  if (!n_live) return FLM_E_ARG;
+  return observations_req_columns_impl(cols, req_agent, own_cols, own_row, n_max, n_live, E, A, Rp, T1, plane_stride, out,
+                                       stream);
 }
 
 extern "C" int flm_observations_req_columns_rows(const int16_t* cols, const int32_t* req_agent, const int32_t* out_row,
@@ -757,7 +775,7 @@ extern "C" int flm_observations_req_columns_rows(const int16_t* cols, const int3
     const int cnt = n_req - lo < 65535 ? n_req - lo : 65535;
     dim3 grid((plane_stride + tile - 1) / tile, cnt);
     hipLaunchKernelGGL(flm::observations_req_columns_kernel, grid, dim3(256), 3 * (size_t)tile, (hipStream_t)stream, cols,
-                       req_agent + lo, nullptr, nullptr, A, T1, plane_stride, tile, out_row + lo, out);
+                       req_agent + lo, nullptr, nullptr, A, T1, plane_stride, tile, out_row + lo, out, nullptr);
     FLM_CHECK_LAUNCH();
   }
   return FLM_OK;

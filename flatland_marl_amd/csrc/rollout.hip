@@ -31,13 +31,20 @@ __global__ __launch_bounds__(64) void altpaths_kernel(
     const int32_t* __restrict__ pos_cell, const int32_t* __restrict__ direction,
     const int32_t* __restrict__ target_cell, int A, int H, int W, int capCells, int max_depth, int cap_alt, int Lcap,
     int G, int32_t* __restrict__ alt_count, int32_t* __restrict__ alt_len, int32_t* __restrict__ alt_cell,
-    uint32_t* __restrict__ alt_meta, int32_t* __restrict__ err_out) {
+    uint32_t* __restrict__ alt_meta, int32_t* __restrict__ err_out, const int32_t* __restrict__ n_live, int live_base,
+    int32_t* __restrict__ agent_rep) {
   __shared__ int s_cell[64], s_h[64], s_base[64], s_res[64], s_n[64], s_err[64], s_cnt[64];
   extern __shared__ __attribute__((aligned(16))) int alt_frames[];     // [64 / G][FLM_ALT_FRAME_INTS], then the staged table
   const int lane = threadIdx.x, grp = lane / G, j = lane - grp * G;
   const int g = blockIdx.x * (64 / G) + grp;
+  // n_live (optional): the launch was sized before the number of requests was known to the host; the kernel that
+  // counted them left it at *n_live, and this launch covers requests live_base .. live_base + n_req - 1 of them
+  if (n_live) n_req = min(n_req, max(*n_live - live_base, 0));
+  if (STAGE && blockIdx.x >= n_req) return;                            // (one request per workgroup)
   const bool live = g < n_req;
   const int ga = live ? req_agent[g] : 0;
+  // agent_rep (optional) [n_req, cap_alt]: the request's agent once per alternative, the list flm_columns takes
+  if (agent_rep && live && j < cap_alt) agent_rep[(size_t)g * cap_alt + j] = ga;
   const int e = ga / A;
   const int HW = H * W;
   const uint16_t* grid = grid_all + (size_t)e * HW;
@@ -478,12 +485,13 @@ __global__ __launch_bounds__(256) void update_bitmaps_kernel(int8_t* __restrict_
 
 }  // namespace flm
 
-extern "C" int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const uint16_t* dist, const uint16_t* succ,
-                            const uint16_t* choice, const int32_t* idx_cell, const int32_t* tslot, const int32_t* node_id,
-                            const int32_t* req_agent, int n_req, const int32_t* pos_cell,
-                            const int32_t* direction, const int32_t* target_cell, int E, int A, int H, int W,
-                            int capCells, int max_depth, int cap_alt, int Lcap, int32_t* alt_count, int32_t* alt_len,
-                            int32_t* alt_cell, uint32_t* alt_meta, int32_t* err, void* stream) {
+static int altpaths_impl(const uint16_t* grid, const int32_t* cell_idx, const uint16_t* dist, const uint16_t* succ,
+                         const uint16_t* choice, const int32_t* idx_cell, const int32_t* tslot, const int32_t* node_id,
+                         const int32_t* req_agent, int n_req, const int32_t* n_live, int live_base, int32_t* agent_rep,
+                         const int32_t* pos_cell,
+                         const int32_t* direction, const int32_t* target_cell, int E, int A, int H, int W,
+                         int capCells, int max_depth, int cap_alt, int Lcap, int32_t* alt_count, int32_t* alt_len,
+                         int32_t* alt_cell, uint32_t* alt_meta, int32_t* err, void* stream) {
   if (!grid || !cell_idx || !dist || !tslot || !node_id || !req_agent || !pos_cell || !direction || !target_cell ||
       !alt_count || !alt_len || !alt_cell || !alt_meta || !err)
     return FLM_E_ARG;
@@ -502,7 +510,8 @@ extern "C" int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const
     FLM_RAISE_LDS_ONCE(flm::altpaths_kernel<true>);
     hipLaunchKernelGGL(flm::altpaths_kernel<true>, dim3(n_req), dim3(64), staged_lds, (hipStream_t)stream, grid, cell_idx,
                        dist, succ, choice, idx_cell, tslot, node_id, req_agent, n_req, pos_cell, direction, target_cell, A, H, W,
-                       capCells, max_depth, cap_alt, Lcap, 64, alt_count, alt_len, alt_cell, alt_meta, err);
+                       capCells, max_depth, cap_alt, Lcap, 64, alt_count, alt_len, alt_cell, alt_meta, err, n_live, live_base,
+                       agent_rep);
   } else {
     const int per_block = 64 / G;
     const size_t lds = (size_t)per_block * FLM_ALT_FRAME_INTS * sizeof(int);
@@ -511,10 +520,34 @@ extern "C" int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const
     hipLaunchKernelGGL(flm::altpaths_kernel<false>, dim3((n_req + per_block - 1) / per_block), dim3(64), lds,
                        (hipStream_t)stream, grid, cell_idx, dist, succ, choice, idx_cell, tslot, node_id, req_agent, n_req, pos_cell,
                        direction, target_cell, A, H, W, capCells, max_depth, cap_alt, Lcap, G, alt_count, alt_len, alt_cell,
-                       alt_meta, err);
+                       alt_meta, err, n_live, live_base, agent_rep);
   }
   FLM_CHECK_LAUNCH();
   return FLM_OK;
+}
+
+extern "C" int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const uint16_t* dist, const uint16_t* succ,
+                            const uint16_t* choice, const int32_t* idx_cell, const int32_t* tslot, const int32_t* node_id,
+                            const int32_t* req_agent, int n_req, const int32_t* pos_cell,
+                            const int32_t* direction, const int32_t* target_cell, int E, int A, int H, int W,
+                            int capCells, int max_depth, int cap_alt, int Lcap, int32_t* alt_count, int32_t* alt_len,
+                            int32_t* alt_cell, uint32_t* alt_meta, int32_t* err, void* stream) {
+  return altpaths_impl(grid, cell_idx, dist, succ, choice, idx_cell, tslot, node_id, req_agent, n_req, nullptr, 0, nullptr, pos_cell,
+                       direction, target_cell, E, A, H, W, capCells, max_depth, cap_alt, Lcap, alt_count, alt_len, alt_cell,
+                       alt_meta, err, stream);
+}
+
+extern "C" int flm_altpaths_counted(const uint16_t* grid, const int32_t* cell_idx, const uint16_t* dist, const uint16_t* succ,
+                                    const uint16_t* choice, const int32_t* idx_cell, const int32_t* tslot,
+                                    const int32_t* node_id, const int32_t* req_agent, int n_max, const int32_t* n_live,
+                                    int live_base, int32_t* agent_rep, const int32_t* pos_cell, const int32_t* direction,
+                                    const int32_t* target_cell, int E, int A, int H, int W, int capCells, int max_depth,
+                                    int cap_alt, int Lcap, int32_t* alt_count, int32_t* alt_len, int32_t* alt_cell,
+                                    uint32_t* alt_meta, int32_t* err, void* stream) {
+  if (!n_live || live_base < 0) return FLM_E_ARG;
+  return altpaths_impl(grid, cell_idx, dist, succ, choice, idx_cell, tslot, node_id, req_agent, n_max, n_live, live_base,
+                       agent_rep, pos_cell, direction, target_cell, E, A, H, W, capCells, max_depth, cap_alt, Lcap, alt_count, alt_len,
+                       alt_cell, alt_meta, err, stream);
 }
 
 extern "C" int flm_check_crash(const int8_t* maps, const int32_t* status, const int32_t* tpc, const int32_t* pos_cell,

@@ -94,22 +94,23 @@ class Dueling_DQN(nn.Module):
              torch.cuda.current_stream(flat.device).cuda_stream)
         return q
 
-    def forward_obs(self, obs_u8, plane_stride, rails_used=0, out=None, flat=None):
+    def forward_obs(self, obs_u8, plane_stride, rails_used=0, out=None, flat=None, stream=None):
         """Q-values [n,action_space] straight from uint8 observations [n,3,plane_stride] (plane 0 int8, heat planes uint8,
         rows of `width` bytes): the convolution reads the bytes, no float copy of the input is made.
         rails_used > 0: the caller vouches that rails rails_used.. of every plane are empty (the padding up to
         max_rails); they are then not computed but enter through the first dense layer's bias.
-        out: a float32 buffer of at least n rows for the result; flat: what flat_params() returned a moment ago (a
-        caller in a hurry asks for it ahead of time)."""
+        out: a float32 buffer of at least n rows for the result; flat: what flat_params() returned a moment ago;
+        stream: the raw stream to launch on (a caller in a hurry has these at hand)."""
         if flat is None:
             flat = self.flat_params()
         if self.height % 3:
             raise ValueError("observations have three planes: the network height must be 3*max_rails")
-        obs_u8 = obs_u8.contiguous()
+        if not obs_u8.is_contiguous():
+            obs_u8 = obs_u8.contiguous()
         n = obs_u8.size(0)
         q = torch.empty((n, self.action_space), dtype=torch.float32, device=flat.device) if out is None else out[:n]
         call("flm_dqn_forward_u8_rails", ptr(flat), ptr(obs_u8), n, self.height // 3, self.width, int(plane_stride),
              self.action_space, int(rails_used), ptr(self._workspace(n)), ptr(q),
-             torch.cuda.current_stream(flat.device).cuda_stream)
+             torch.cuda.current_stream(flat.device).cuda_stream if stream is None else stream)
         return q
 

@@ -23,6 +23,28 @@ from .batch import ObservationBatch
 MAX_REQ = 65535      # requests per launch of the request kernels
 
 
+class _AltViews(dict):
+    """What RolloutBatch.alternatives returns: views of the pooled tables for n requests, made on first use (a step
+    touches a few of them, and slicing all of them costs more host time than the kernels leave)."""
+    _PER_REQUEST = ("count", "len", "cell", "meta", "err", "cols", "col_err")
+
+    def __init__(self, pool, n, n_rows, req):
+        super().__init__(req=req)
+        self._pool, self._n, self._n_rows = pool, n, n_rows
+
+    def __missing__(self, key):
+        if key in self._PER_REQUEST:
+            v = self._pool[key][:self._n]
+        elif key == "row_offset":
+            v = self._pool[key][:self._n + 1]
+        elif key in ("row_req", "row_own"):
+            v = self._pool[key][:self._n_rows]
+        else:
+            raise KeyError(key)
+        self[key] = v
+        return v
+
+
 class RolloutBatch:
     def __init__(self, batch: ObservationBatch, speed, initial_direction=None, cap_alt=8, max_alt_depth=500,
                  malfunction=None):
@@ -77,9 +99,9 @@ class RolloutBatch:
         self._dummy_i32 = torch.zeros((1,), **i32)
         self._dummy_i16 = torch.zeros((1,), dtype=torch.int16, device=dev)
         self.cols = None
-        self._agent_flat = None
         self._alt_pool = None
         self._rails_used = None             # (of the batch's graphs: asked for again after a reset)
+        self._alt_guess = 0                 # agents before a switch expected in the coming step (0: not yet known)
         self.t = 0
         self.malfunction = self.malfunction_moving = self.env_seed = None
         self.malf_threshold, self.malf_min, self.malf_max = 0, 0, 0
@@ -130,6 +152,7 @@ class RolloutBatch:
             b.compute_distances()
         b.shortest_paths()
         self._rails_used = None
+        self._alt_guess = 0
         self.cols = b.columns(shift=1)
         n = min(b.Lcap, self.Lp)
         self.path_cell[:, :, :n] = b.path_cell[:, :, :n]
@@ -169,45 +192,55 @@ class RolloutBatch:
                 err=torch.empty((cap,), **i32), cols=torch.empty((cap, K, b.T1), dtype=torch.int16, device=self.device),
                 col_err=torch.empty((cap, K), **i32), row_offset=torch.empty((cap + 1,), **i32),
                 row_req=torch.empty((cap_rows,), **i32), row_own=torch.empty((cap_rows,), **i32))
+            pool["agent_rep"] = torch.empty((cap * K,), **i32)
             pool["base"] = tuple(pool[k].data_ptr() for k in ("count", "len", "cell", "meta", "err"))
+            pool["ptrs"] = {k: pool[k].data_ptr() for k in ("cols", "col_err", "row_offset", "row_req", "row_own")}
         return pool
 
-    def alternatives(self, req, ready=None, tables=None):
+    def alternatives(self, req, ready=None, tables=None, launched=0):
         """Alternative paths and their planes (column form) for the agents req[n] (flat e*A+a, all ACTIVE):
         get_altmaps, src/rail_observations.py:97-111.  The batch's pos_cell / direction / status must hold
         the agents' current state (step() sees to it).  ready: the departing agents of the same step; the
         rows the network has to evaluate (ready first, then every alternative) are listed in row_req /
-        row_own, their number in req_counts[2]."""
+        row_own, their number in req_counts[2].  launched: flm_altpaths_counted has already been enqueued for the
+        first so many requests (step() does that before it knows their number), into the current pool.
+        Returns a dict of views of pooled buffers (count, len, cell, meta, err, cols, col_err, row_offset, row_req,
+        row_own) and req; the views are made when they are first asked for."""
         b = self.b
         n, K = req.numel(), self.cap_alt
         n_ready = 0 if ready is None else ready.numel()
+        before = self._alt_pool
         pool = self._alt_pool_for(n, n_ready)
+        if pool is not before:
+            launched = 0                                    # the pool had to grow: what was enqueued wrote into the old one
         fixed, state = tables if tables is not None else self._alt_tables()
         p_count, p_len, p_cell, p_meta, p_err = pool["base"]
         p_req, st, Lp = ptr(req), self.stream, self.Lp
-        for lo in range(0, n, MAX_REQ):
-            call("flm_altpaths", *fixed, p_req + 4 * lo, min(n, lo + MAX_REQ) - lo, *state, self.E, self.A, b.H, b.W, b.cap_cells,
-                 self.max_alt_depth, K, Lp, p_count + 4 * lo, p_len + 4 * K * lo, p_cell + 4 * K * Lp * lo,
-                 p_meta + 4 * K * Lp * lo, p_err + 4 * lo, st)
-        # (the views below are made while the device follows the paths)
-        alt = dict(count=pool["count"][:n], len=pool["len"][:n], cell=pool["cell"][:n], meta=pool["meta"][:n],
-                   err=pool["err"][:n], cols=pool["cols"][:n], col_err=pool["col_err"][:n], req=req,
-                   row_offset=pool["row_offset"][:n + 1], row_req=pool["row_req"][:n_ready + n * K],
-                   row_own=pool["row_own"][:n_ready + n * K])
-        # one path per (request, alternative); unused alternatives have length 0
-        if self._agent_flat is None or self._agent_flat.numel() < n * K:
-            self._agent_flat = torch.empty((max(n * K, 1024),), dtype=torch.int32, device=self.device)
-        agent_flat = self._agent_flat[:n * K]
-        agent_flat.view(n, K).copy_(req[:, None].expand(n, K))
-        call("flm_columns", ptr(alt["cell"]), ptr(alt["len"]), ptr(agent_flat), ptr(b.pos_cell), ptr(b.target_cell),
+        p_rep = pool["agent_rep"].data_ptr()
+        if tables is not None:
+            # inside a step: the kernel that counted the requests is ahead on the stream, the launch takes their number
+            # from there and also writes the per-path agent list
+            for lo in range(min(launched, n), n, MAX_REQ):
+                call("flm_altpaths_counted", *fixed, p_req + 4 * lo, min(n, lo + MAX_REQ) - lo, self.req_counts.data_ptr() + 4, lo,
+                     p_rep + 4 * K * lo, *state, self.E, self.A, b.H, b.W, b.cap_cells, self.max_alt_depth, K, Lp,
+                     p_count + 4 * lo, p_len + 4 * K * lo, p_cell + 4 * K * Lp * lo, p_meta + 4 * K * Lp * lo, p_err + 4 * lo, st)
+        else:
+            for lo in range(0, n, MAX_REQ):
+                call("flm_altpaths", *fixed, p_req + 4 * lo, min(n, lo + MAX_REQ) - lo, *state, self.E, self.A, b.H, b.W,
+                     b.cap_cells, self.max_alt_depth, K, Lp, p_count + 4 * lo, p_len + 4 * K * lo, p_cell + 4 * K * Lp * lo,
+                     p_meta + 4 * K * Lp * lo, p_err + 4 * lo, st)
+            # one path per (request, alternative); unused alternatives have length 0
+            pool["agent_rep"][:n * K].view(n, K).copy_(req[:, None].expand(n, K))
+        ptrs = pool["ptrs"]
+        call("flm_columns", p_cell, p_len, p_rep, ptr(b.pos_cell), ptr(b.target_cell),
              ptr(b.tpc), ptr(b.node_id), ptr(b.cell_rail), ptr(b.edge_info), self.E, self.A, n * K, b.H, b.W, b.capR,
-             b.Rp, b.T1, self.Lp, 0, ptr(alt["cols"]), ptr(alt["col_err"]), self.stream)
+             b.Rp, b.T1, self.Lp, 0, ptrs["cols"], ptrs["col_err"], self.stream)
         # an alternative whose path cannot be mapped on the rail graph raises in the reference; here the agent
         # is flagged and treated as having no alternatives
-        call("flm_rollout_alt_finish", ptr(alt["count"]), ptr(alt["err"]), ptr(alt["col_err"]), ptr(req), n, K,
-             ptr(ready) if n_ready else None, n_ready, ptr(self.agent_err), ptr(alt["row_offset"]),
-             ptr(alt["row_req"]), ptr(alt["row_own"]), ptr(self.req_counts), self.stream)
-        return alt
+        call("flm_rollout_alt_finish", p_count, p_err, ptrs["col_err"], p_req, n, K,
+             ptr(ready) if n_ready else None, n_ready, ptr(self.agent_err), ptrs["row_offset"],
+             ptrs["row_req"], ptrs["row_own"], ptr(self.req_counts), self.stream)
+        return _AltViews(pool, n, n_ready + n * K, req)
 
     def consult_observations(self, req, own_cols=None, out=None, own_row=None):
         """[n,3,plane_stride] uint8 observations of the agents req[n] against the current planes
@@ -227,6 +260,15 @@ class RolloutBatch:
             call("flm_observations_req_columns", ptr(self.cols), p_req + 4 * lo, oc, orow, min(n, lo + MAX_REQ) - lo, self.E,
                  self.A, b.Rp, b.T1, b.plane_stride, p_out + 3 * b.plane_stride * lo, self.stream)
         return out
+
+    def consult_observations_counted(self, req, own_cols, own_row, out, n_max):
+        """consult_observations for the first req_counts[2] of the n_max requests listed in req, enqueued before the
+        host knows that number (the kernel that counted them is ahead on the stream); out holds n_max rows."""
+        b = self.b
+        if n_max > MAX_REQ:
+            raise ValueError("at most %d requests per launch" % MAX_REQ)
+        call("flm_observations_req_columns_counted", ptr(self.cols), ptr(req), ptr(own_cols), ptr(own_row), n_max,
+             self.req_counts.data_ptr() + 8, self.E, self.A, b.Rp, b.T1, b.plane_stride, ptr(out), self.stream)
 
     def apply(self, net_in, best, alt):
         b = self.b
@@ -274,9 +316,21 @@ class RolloutBatch:
         prepare = getattr(policy, "prepare", None)
         if prepare is not None:
             prepare(self)
-        n_ready, n_switch = self.read_counts()[:2]             # the host waits for the step's sizes
+        # ... and the alternative paths are enqueued for about as many agents as asked in the last step: the kernel takes
+        # the real number from where the kernel above left it, the host learns it while the paths are being followed,
+        # and whoever was not covered gets a launch of their own
+        self.mark_counts()
+        launched = min(self._alt_guess, self.E * self.A, MAX_REQ)
+        if launched:
+            pool = self._alt_pool_for(launched, 0)
+            p_count, p_len, p_cell, p_meta, p_err = pool["base"]
+            call("flm_altpaths_counted", *tables[0], ptr(self.switch_list), launched, self.req_counts.data_ptr() + 4, 0,
+                 pool["agent_rep"].data_ptr(), *tables[1], self.E, self.A, b.H, b.W, b.cap_cells, self.max_alt_depth, self.cap_alt, self.Lp, p_count, p_len,
+                 p_cell, p_meta, p_err, self.stream)
+        n_ready, n_switch = self.wait_counts()[:2]             # the host waits for the step's sizes
+        self._alt_guess = n_switch + n_switch // 4 + 32 if n_switch else 0
         req_ready, req_switch = self.ready_list[:n_ready], self.switch_list[:n_switch]
-        alt = self.alternatives(req_switch, req_ready, tables) if n_switch else None
+        alt = self.alternatives(req_switch, req_ready, tables, launched) if n_switch else None
         info = dict(t=self.t, branch=self.branch, req_ready=req_ready, req_switch=req_switch, alt=alt,
                     net=self._net, best=self._best)
         net_in, best = policy(self, info)
@@ -293,11 +347,18 @@ class RolloutBatch:
             self._rails_used = int(np.asarray(self.b.R).max())
         return self._rails_used
 
-    def read_counts(self):
-        """[departing agents, agents before a switch, network rows] as the kernels enqueued so far leave them."""
+    def mark_counts(self):
+        """The point of the stream at which wait_counts() reads the step's sizes: behind the kernels enqueued so far."""
         self._counts_event.record(self.b.stream)
+
+    def wait_counts(self):
         self._counts_event.synchronize()
         return self.req_counts.tolist()
+
+    def read_counts(self):
+        """[departing agents, agents before a switch, network rows] as the kernels enqueued so far leave them."""
+        self.mark_counts()
+        return self.wait_counts()
 
     def flagged_agents(self):
         """(agents whose path or alternatives raised in the reference's terms, agents that hit a capacity of this

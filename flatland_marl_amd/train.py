@@ -26,7 +26,7 @@ import torch
 from . import parallel
 from ._lib import call, ptr, query
 from .replay import DeviceReplay
-from .rollout import RolloutBatch
+from .rollout import MAX_REQ, RolloutBatch
 
 
 def obs_to_f32(obs_u8, Rp, T1, plane_stride, out=None):
@@ -65,7 +65,8 @@ class DQNPolicy:
         net = self.agent.qnetwork_local
         rails = ro.rails_used()                            # rails beyond these are padding in every observation
         if n <= chunk:
-            return net.forward_obs(obs_u8, b.plane_stride, rails, out=out, flat=flat)
+            # (on the stream the rollout's kernels run on: the observations were written there)
+            return net.forward_obs(obs_u8, b.plane_stride, rails, out=out, flat=flat, stream=ro.stream)
         q = torch.empty((n, 2), dtype=torch.float32, device=obs_u8.device) if out is None else out[:n]
         for lo in range(0, n, chunk):
             hi = min(n, lo + chunk)
@@ -100,11 +101,22 @@ class DQNPolicy:
             self.prepare(ro)
         flat, self._flat = self._flat, None
         if alt is not None:
-            rows = ro.read_counts()[2]                     # departing agents + all alternatives
-            if rows:
-                obs_pool, q_pool = self._rows_pool(ro, rows)
-                obs = ro.consult_observations(alt["row_req"][:rows], alt["cols"].view(-1, ro.b.T1), out=obs_pool[:rows],
-                                              own_row=alt["row_own"][:rows])
+            # departing agents + all alternatives: at most n1 + n2 * cap_alt rows.  The observations are enqueued for that
+            # many (the kernel skips the rows beyond the number its predecessor counted), then the host waits for the number
+            rows_max = n1 + n2 * ro.cap_alt
+            if rows_max <= MAX_REQ:
+                obs_pool, q_pool = self._rows_pool(ro, rows_max)
+                ro.mark_counts()
+                pool = ro._alt_pool                         # (the tables of this step's alternatives, whole buffers)
+                ro.consult_observations_counted(pool["row_req"], pool["cols"], pool["row_own"], obs_pool, rows_max)
+                rows = ro.wait_counts()[2]
+                obs = obs_pool[:rows]
+            else:
+                rows = ro.read_counts()[2]
+                if rows:
+                    obs_pool, q_pool = self._rows_pool(ro, rows)
+                    obs = ro.consult_observations(alt["row_req"][:rows], alt["cols"].view(-1, ro.b.T1), out=obs_pool[:rows],
+                                                  own_row=alt["row_own"][:rows])
         else:
             rows = n1
             obs_pool, q_pool = self._rows_pool(ro, rows)

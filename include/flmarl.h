@@ -250,6 +250,13 @@ int flm_observations_req(const int8_t* maps, const int32_t* req_agent, const int
 int flm_observations_req_columns(const int16_t* cols, const int32_t* req_agent, const int16_t* own_cols,
                                  const int32_t* own_row, int n_req, int E, int A, int Rp, int T1, int plane_stride,
                                  uint8_t* out, void* stream);
+/* The same launch sized before the host knows the number of requests: n_max is an upper bound, *n_live (memory the
+ * device can read, written by the kernel that counted the requests - flm_rollout_alt_finish's counts[2] - earlier on
+ * the same stream) their number; requests from *n_live on are skipped.  out holds n_max rows.  A caller uses it to
+ * enqueue the observations first and wait for the count afterwards, instead of leaving the device idle meanwhile. */
+int flm_observations_req_columns_counted(const int16_t* cols, const int32_t* req_agent, const int16_t* own_cols,
+                                         const int32_t* own_row, int n_max, const int32_t* n_live, int E, int A, int Rp,
+                                         int T1, int plane_stride, uint8_t* out, void* stream);
 
 /* flm_observations_req_columns of the agents' own planes, written to chosen rows: request g goes to row
  * out_row[g] of out [.,3,plane_stride] (a negative out_row[g] skips the request).  The training loop's
@@ -289,6 +296,17 @@ int flm_altpaths(const uint16_t* grid, const int32_t* cell_idx, const uint16_t* 
                  const int32_t* direction, const int32_t* target_cell, int E, int A, int H, int W, int capCells,
                  int max_depth, int cap_alt, int Lcap, int32_t* alt_count, int32_t* alt_len, int32_t* alt_cell,
                  uint32_t* alt_meta, int32_t* err, void* stream);
+/* flm_altpaths sized before the host knows the number of requests (see flm_observations_req_columns_counted): the
+ * launch covers requests live_base .. live_base + n_max - 1 of the *n_live that flm_rollout_requests counted
+ * (counts[1]); req_agent and the outputs point at request live_base.  Requests beyond *n_live are not touched.
+ * agent_rep (optional) [n_max,cap_alt] int32: the request's agent once per alternative, the agent list flm_columns takes
+ * for the paths in alt_cell. */
+int flm_altpaths_counted(const uint16_t* grid, const int32_t* cell_idx, const uint16_t* dist, const uint16_t* succ,
+                         const uint16_t* choice, const int32_t* idx_cell, const int32_t* tslot, const int32_t* node_id,
+                         const int32_t* req_agent, int n_max, const int32_t* n_live, int live_base, int32_t* agent_rep,
+                         const int32_t* pos_cell, const int32_t* direction, const int32_t* target_cell, int E, int A, int H,
+                         int W, int capCells, int max_depth, int cap_alt, int Lcap, int32_t* alt_count, int32_t* alt_len,
+                         int32_t* alt_cell, uint32_t* alt_meta, int32_t* err, void* stream);
 
 /* Would the selected agent of each environment crash if it moved now?
  * Replaces RailObsForRailEnv.check_crash with _is_cell_occupied, _check_headon_crash, _last_train_on_rail
