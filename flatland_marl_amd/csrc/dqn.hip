@@ -1044,8 +1044,37 @@ __global__ __launch_bounds__(1024) void head_backward_fused_kernel(
       dhid[(long)m * 1024 + n] = out;
       return out;
     };
+    // (the activations of eight rows are fetched before the first of them is used: the loop is a chain of loads otherwise)
+    auto fetch = [&](int m) -> float { return hid[(long)m * 1024 + n]; };
+    auto row_with = [&](int m, float h) -> float {
+      float g;
+      if (adv) {
+        g = s_da[0][m] * wcol[0];
+#pragma unroll
+        for (int a = 1; a < FLM_DQN_MAX_ACTIONS; a++)
+          if (a < NA) g = fmaf(s_da[a][m], wcol[a], g);
+      } else {
+        g = s_dv[m] * wcol[0];
+      }
+      const float out = h > 0.f ? g : 0.f;
+      dhid[(long)m * 1024 + n] = out;
+      return out;
+    };
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int m = w;
+    for (; m + 112 < B; m += 128) {
+      float h[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) h[u] = fetch(m + 16 * u);
+      a0 += row_with(m, h[0]);
+      a1 += row_with(m + 16, h[1]);
+      a2 += row_with(m + 32, h[2]);
+      a3 += row_with(m + 48, h[3]);
+      a0 += row_with(m + 64, h[4]);
+      a1 += row_with(m + 80, h[5]);
+      a2 += row_with(m + 96, h[6]);
+      a3 += row_with(m + 112, h[7]);
+    }
     for (; m + 48 < B; m += 64) {
       a0 += row(m);
       a1 += row(m + 16);
@@ -1069,7 +1098,16 @@ __global__ __launch_bounds__(1024) void head_backward_fused_kernel(
     const bool value = a == NA;
     const float* d = value ? s_dv : s_da[a];
     float acc = 0.f;
-    for (int b = w; b < B; b += 16) acc = fmaf(d[b], hid[(long)b * 1024 + (value ? 512 : 0) + i], acc);
+    const float* hcol = hid + (value ? 512 : 0) + i;
+    int b = w;
+    for (; b + 112 < B; b += 128) {                  // eight loads in flight, the products added in the order of the samples
+      float h[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) h[u] = hcol[(long)(b + 16 * u) * 1024];
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc = fmaf(d[b + 16 * u], h[u], acc);
+    }
+    for (; b < B; b += 16) acc = fmaf(d[b], hcol[(long)b * 1024], acc);
     s_red[w][lane] = acc;
     __syncthreads();
     if (w == 0) {
