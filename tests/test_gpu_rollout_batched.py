@@ -106,3 +106,72 @@ def replay_against(fx, gold):
             assert np.array_equal(maps, dense_from_runs(gold["snap_%d" % t], maps.shape)), t
     assert obs_h.hexdigest() == str(gold["obs_sha"])
     assert not ro.agent_err.any()
+
+
+def test_counted_launches_match_the_sized_ones():
+    """flm_altpaths_counted / flm_observations_req_columns_counted (sized by an upper bound, the real number read on the
+    device) against flm_altpaths / flm_observations_req_columns on the same requests some steps into an episode: the
+    same bits for the requests that exist, nothing written for the rest, the per-path agent list as the host would
+    build it; and a launch that covers only the tail of the requests (live_base > 0)."""
+    import torch
+    from flatland_marl_amd._lib import call, ptr
+    from flatland_marl_amd.rollout import hash_policy
+    fx = load_env("Test_3_Level_0")
+    A = 14
+    ro = _rollout(fx, A, 60, 160, 5)
+    b = ro.b
+    for _ in range(25):
+        ro.step(hash_policy)
+    ro.classify()
+    call("flm_rollout_requests", ptr(ro.branch), ptr(ro.status), ptr(ro.pos), ptr(ro.heading), ptr(b.start_cell), ro.E, ro.A,
+         ptr(ro.ready_list), ptr(ro.switch_list), ptr(ro.req_counts), ptr(ro.alt_slot), ptr(ro._net), ptr(ro._best),
+         ptr(b.pos_cell), ptr(b.direction), ptr(b.status), ptr(ro._req_ws), ro.stream)
+    n_ready, n = ro.read_counts()[:2]
+    assert n >= 4
+    req = ro.switch_list[:n].clone()
+    K, Lp, dev = ro.cap_alt, ro.Lp, ro.device
+    n_max = n + 7
+    i32 = dict(dtype=torch.int32, device=dev)
+
+    def tables():
+        return dict(count=torch.full((n_max,), -7, **i32), len=torch.full((n_max, K), -7, **i32),
+                    cell=torch.full((n_max, K, Lp), -7, **i32), meta=torch.full((n_max, K, Lp), -7, **i32),
+                    err=torch.full((n_max,), -7, **i32))
+    fixed, state = ro._alt_tables()
+    tail = (ro.E, ro.A, b.H, b.W, b.cap_cells, ro.max_alt_depth, K, Lp)
+    want, got, got2 = tables(), tables(), tables()
+    call("flm_altpaths", *fixed, ptr(req), n, *state, *tail, ptr(want["count"]), ptr(want["len"]), ptr(want["cell"]),
+         ptr(want["meta"]), ptr(want["err"]), ro.stream)
+    live = torch.tensor([n], **i32)
+    rep = torch.full((n_max, K), -7, **i32)
+    req_pad = torch.cat([req, torch.full((7,), 10 ** 6, **i32)])            # what lies beyond the list must not be read
+    call("flm_altpaths_counted", *fixed, ptr(req_pad), n_max, ptr(live), 0, ptr(rep), *state, *tail, ptr(got["count"]),
+         ptr(got["len"]), ptr(got["cell"]), ptr(got["meta"]), ptr(got["err"]), ro.stream)
+    # the tail alone: requests lo.. of the n, through pointers that start at request lo
+    lo = n // 2
+    call("flm_altpaths_counted", *fixed, req_pad.data_ptr() + 4 * lo, n_max - lo, ptr(live), lo, None, *state, *tail,
+         got2["count"].data_ptr() + 4 * lo, got2["len"].data_ptr() + 4 * K * lo, got2["cell"].data_ptr() + 4 * K * Lp * lo,
+         got2["meta"].data_ptr() + 4 * K * Lp * lo, got2["err"].data_ptr() + 4 * lo, ro.stream)
+    torch.cuda.synchronize()
+    cnt = want["count"][:n]
+    assert int(cnt.max()) >= 2
+    for k in ("count", "err"):
+        assert torch.equal(got[k][:n], want[k][:n]) and bool((got[k][n:] == -7).all())
+        assert torch.equal(got2[k][lo:n], want[k][lo:n]) and bool((got2[k][:lo] == -7).all()) and bool((got2[k][n:] == -7).all())
+    assert torch.equal(got["len"][:n], want["len"][:n]) and torch.equal(got2["len"][lo:n], want["len"][lo:n])
+    used = torch.arange(Lp, device=dev)[None, None, :] < want["len"][:n, :, None]     # the elements of existing paths
+    for k in ("cell", "meta"):
+        assert torch.equal(got[k][:n][used], want[k][:n][used]) and bool((got[k][n:] == -7).all())
+        assert torch.equal(got2[k][lo:n][used[lo:]], want[k][lo:n][used[lo:]])
+    assert torch.equal(rep[:n], req[:, None].expand(n, K)) and bool((rep[n:] == -7).all())
+    # observations: the departing agents' own planes, sized by an upper bound
+    m = n_ready + n
+    agents = torch.cat([ro.ready_list[:n_ready], req])
+    want_o = ro.consult_observations(agents)
+    got_o = torch.full((m + 5, 3, b.plane_stride), 9, dtype=torch.uint8, device=dev)
+    live_o = torch.tensor([m], **i32)
+    agents_pad = torch.cat([agents, torch.full((5,), 10 ** 6, **i32)])
+    call("flm_observations_req_columns_counted", ptr(ro.cols), ptr(agents_pad), None, None, m + 5, ptr(live_o), ro.E, ro.A,
+         b.Rp, b.T1, b.plane_stride, ptr(got_o), ro.stream)
+    torch.cuda.synchronize()
+    assert torch.equal(got_o[:m], want_o) and bool((got_o[m:] == 9).all()) and int(want_o.max()) > 0
