@@ -41,7 +41,7 @@ _SIGNATURES = {
     "flm_observations_req": [_p, _p, _p, _i, _i, _i, _i, _p, _p],
     "flm_reorder_rails": [_p, _p, _i, _i, _i, _i, _p, _p],
     "flm_observations_req_columns": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
-    "flm_observations_req_columns_counted": [_p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p],
+    "flm_observations_req_columns_counted": [_p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "flm_rollout_requests": [_p] * 5 + [_i, _i] + [_p] * 11,
     "flm_rollout_alt_finish": [_p] * 4 + [_i, _i, _p, _i] + [_p] * 6,
     "flm_policy_select": [_p, _p, _i, _p, _i, _p, _p, C.c_double, _u32, _i, _p, _p, _p, _p, _p],

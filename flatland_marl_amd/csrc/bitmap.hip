@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void observations_req_columns_kernel(const int
                                                                        int plane_stride, int tile_bytes,
                                                                        const int32_t* __restrict__ out_row,
                                                                        uint8_t* __restrict__ out,
-                                                                       const int32_t* __restrict__ n_live) {
+                                                                       const int32_t* __restrict__ n_live, int plane_limit) {
   extern __shared__ __attribute__((aligned(16))) unsigned req_tile[];   // [3][tile_bytes/4]: own plane, positive heat, negative heat (packed bytes)
   const int g = blockIdx.y, tid = threadIdx.x;
   // n_live (optional): the launch was sized by an upper bound; the kernel that counted the requests left their number there
@@ -494,7 +494,8 @@ __global__ __launch_bounds__(256) void observations_req_columns_kernel(const int
     if (p >= 0 && p < tile_bytes) reinterpret_cast<unsigned char*>(req_tile)[p] = (c & 1) ? (unsigned char)1 : (unsigned char)0xff;
   }
   __syncthreads();
-  const int n16 = min(tile_bytes, plane_stride - p0) / 16;
+  // (plane_limit <= plane_stride: the bytes of every plane that are written; the caller keeps the rest)
+  const int n16 = min(tile_bytes, plane_limit - p0) / 16;
   uint8_t* o = out + (size_t)dst_row * 3 * plane_stride + p0;
   for (int i = tid; i < n16; i += 256) {
     reinterpret_cast<uint4*>(o)[i] = reinterpret_cast<const uint4*>(req_tile)[i];
@@ -734,16 +735,18 @@ extern "C" int flm_observations_req(const int8_t* maps, const int32_t* req_agent
 }
 
 static int observations_req_columns_impl(const int16_t* cols, const int32_t* req_agent, const int16_t* own_cols,
-                                         const int32_t* own_row, int n_req, const int32_t* n_live, int E, int A, int Rp,
-                                         int T1, int plane_stride, uint8_t* out, void* stream) {
+                                         const int32_t* own_row, int n_req, const int32_t* n_live, int plane_limit, int E,
+                                         int A, int Rp, int T1, int plane_stride, uint8_t* out, void* stream) {
   if (!cols || !req_agent || !out) return FLM_E_ARG;
+  if (plane_limit < 0 || plane_limit > plane_stride || plane_limit % 16 != 0) return FLM_E_ARG;
+  if (plane_limit == 0) plane_limit = plane_stride;
   if (n_req <= 0 || n_req > 65535 || E <= 0 || A <= 0 || A > 255 || Rp <= 0 || T1 <= 0 || plane_stride % 16 != 0 ||
       (long long)plane_stride < (long long)Rp * T1)
     return FLM_E_ARG;
-  const int tile = plane_stride < FLM_REQ_TILE ? plane_stride : FLM_REQ_TILE;      // a multiple of 16
-  dim3 grid((plane_stride + tile - 1) / tile, n_req);
+  const int tile = plane_limit < FLM_REQ_TILE ? plane_limit : FLM_REQ_TILE;        // a multiple of 16
+  dim3 grid((plane_limit + tile - 1) / tile, n_req);
   hipLaunchKernelGGL(flm::observations_req_columns_kernel, grid, dim3(256), 3 * (size_t)tile, (hipStream_t)stream, cols,
-                     req_agent, own_cols, own_row, A, T1, plane_stride, tile, nullptr, out, n_live);
+                     req_agent, own_cols, own_row, A, T1, plane_stride, tile, nullptr, out, n_live, plane_limit);
   FLM_CHECK_LAUNCH();
   return FLM_OK;
 }
@@ -751,16 +754,17 @@ static int observations_req_columns_impl(const int16_t* cols, const int32_t* req
 extern "C" int flm_observations_req_columns(const int16_t* cols, const int32_t* req_agent, const int16_t* own_cols,
                                             const int32_t* own_row, int n_req, int E, int A, int Rp, int T1,
                                             int plane_stride, uint8_t* out, void* stream) {
-  return observations_req_columns_impl(cols, req_agent, own_cols, own_row, n_req, nullptr, E, A, Rp, T1, plane_stride, out,
-                                       stream);
+  return observations_req_columns_impl(cols, req_agent, own_cols, own_row, n_req, nullptr, 0, E, A, Rp, T1, plane_stride,
+                                       out, stream);
 }
 
 extern "C" int flm_observations_req_columns_counted(const int16_t* cols, const int32_t* req_agent, const int16_t* own_cols,
-                                                    const int32_t* own_row, int n_max, const int32_t* n_live, int E, int A,
-                                                    int Rp, int T1, int plane_stride, uint8_t* out, void* stream) {
+                                                    const int32_t* own_row, int n_max, const int32_t* n_live,
+                                                    int plane_limit, int E, int A, int Rp, int T1, int plane_stride,
+                                                    uint8_t* out, void* stream) {
   if (!n_live) return FLM_E_ARG;
-  return observations_req_columns_impl(cols, req_agent, own_cols, own_row, n_max, n_live, E, A, Rp, T1, plane_stride, out,
-                                       stream);
+  return observations_req_columns_impl(cols, req_agent, own_cols, own_row, n_max, n_live, plane_limit, E, A, Rp, T1,
+                                       plane_stride, out, stream);
 }
 
 extern "C" int flm_observations_req_columns_rows(const int16_t* cols, const int32_t* req_agent, const int32_t* out_row,
@@ -775,7 +779,7 @@ extern "C" int flm_observations_req_columns_rows(const int16_t* cols, const int3
     const int cnt = n_req - lo < 65535 ? n_req - lo : 65535;
     dim3 grid((plane_stride + tile - 1) / tile, cnt);
     hipLaunchKernelGGL(flm::observations_req_columns_kernel, grid, dim3(256), 3 * (size_t)tile, (hipStream_t)stream, cols,
-                       req_agent + lo, nullptr, nullptr, A, T1, plane_stride, tile, out_row + lo, out, nullptr);
+                       req_agent + lo, nullptr, nullptr, A, T1, plane_stride, tile, out_row + lo, out, nullptr, plane_stride);
     FLM_CHECK_LAUNCH();
   }
   return FLM_OK;

@@ -261,14 +261,21 @@ class RolloutBatch:
                  self.A, b.Rp, b.T1, b.plane_stride, p_out + 3 * b.plane_stride * lo, self.stream)
         return out
 
-    def consult_observations_counted(self, req, own_cols, own_row, out, n_max):
+    def consult_observations_counted(self, req, own_cols, own_row, out, n_max, plane_limit=0):
         """consult_observations for the first req_counts[2] of the n_max requests listed in req, enqueued before the
-        host knows that number (the kernel that counted them is ahead on the stream); out holds n_max rows."""
+        host knows that number (the kernel that counted them is ahead on the stream); out holds n_max rows.
+        plane_limit > 0: only so many bytes of every plane are written (plane_bytes_used()); out must hold zeros
+        behind them."""
         b = self.b
         if n_max > MAX_REQ:
             raise ValueError("at most %d requests per launch" % MAX_REQ)
         call("flm_observations_req_columns_counted", ptr(self.cols), ptr(req), ptr(own_cols), ptr(own_row), n_max,
-             self.req_counts.data_ptr() + 8, self.E, self.A, b.Rp, b.T1, b.plane_stride, ptr(out), self.stream)
+             self.req_counts.data_ptr() + 8, int(plane_limit), self.E, self.A, b.Rp, b.T1, b.plane_stride, ptr(out), self.stream)
+
+    def plane_bytes_used(self):
+        """Bytes at the start of every observation plane that can be other than zero: the rails the batch's
+        environments have, rounded up to 16 bytes."""
+        return min(self.b.plane_stride, (self.rails_used() * self.b.T1 + 15) // 16 * 16)
 
     def apply(self, net_in, best, alt):
         b = self.b

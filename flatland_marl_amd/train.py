@@ -56,6 +56,7 @@ class DQNPolicy:
         self._raw = None
         self._last = None
         self._flat = self._sel = self._pool = None
+        self._pool_limit = 0
 
     def q_values(self, ro, obs_u8, out=None, flat=None):
         b = ro.b
@@ -81,13 +82,16 @@ class DQNPolicy:
             self._sel = tuple(torch.empty((ro.E * ro.A,), dtype=torch.int32, device=ro.device) for _ in range(2))
 
     def _rows_pool(self, ro, rows):
-        """Observation rows and Q-values of a step: buffers that only grow."""
+        """Observation rows and Q-values of a step: buffers that only grow.  The observation rows start as zeros, and
+        self._pool_limit is how many bytes of every plane have been written since: a step that writes fewer bytes per
+        plane than an earlier one (another batch of environments with fewer rails) clears them first."""
         pool = self._pool
-        if pool is None or pool[0].shape[0] < rows or pool[0].device != ro.device:
+        if pool is None or pool[0].shape[0] < rows or pool[0].device != ro.device or pool[0].shape[2] != ro.b.plane_stride:
             self._pool = pool = None                        # (release before taking larger ones)
             cap = rows + rows // 4 + 64
-            self._pool = pool = (torch.empty((cap, 3, ro.b.plane_stride), dtype=torch.uint8, device=ro.device),
+            self._pool = pool = (torch.zeros((cap, 3, ro.b.plane_stride), dtype=torch.uint8, device=ro.device),
                                  torch.empty((cap, 2), dtype=torch.float32, device=ro.device))
+            self._pool_limit = 0
         return pool
 
     def __call__(self, ro, info):
@@ -108,7 +112,12 @@ class DQNPolicy:
                 obs_pool, q_pool = self._rows_pool(ro, rows_max)
                 ro.mark_counts()
                 pool = ro._alt_pool                         # (the tables of this step's alternatives, whole buffers)
-                ro.consult_observations_counted(pool["row_req"], pool["cols"], pool["row_own"], obs_pool, rows_max)
+                # only the rails the environments have are written: the rest of every plane is zero and stays so
+                limit = ro.plane_bytes_used()
+                if limit < self._pool_limit:
+                    obs_pool.zero_()
+                self._pool_limit = limit
+                ro.consult_observations_counted(pool["row_req"], pool["cols"], pool["row_own"], obs_pool, rows_max, limit)
                 rows = ro.wait_counts()[2]
                 obs = obs_pool[:rows]
             else:
@@ -117,10 +126,12 @@ class DQNPolicy:
                     obs_pool, q_pool = self._rows_pool(ro, rows)
                     obs = ro.consult_observations(alt["row_req"][:rows], alt["cols"].view(-1, ro.b.T1), out=obs_pool[:rows],
                                                   own_row=alt["row_own"][:rows])
+                    self._pool_limit = ro.b.plane_stride
         else:
             rows = n1
             obs_pool, q_pool = self._rows_pool(ro, rows)
             obs = ro.consult_observations(req1, out=obs_pool[:rows])
+            self._pool_limit = ro.b.plane_stride            # (whole planes written)
         if rows == 0:                                       # agents before a switch, none with an alternative
             return net, best
         q = self.q_values(ro, obs, out=q_pool, flat=flat)

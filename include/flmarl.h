@@ -253,10 +253,13 @@ int flm_observations_req_columns(const int16_t* cols, const int32_t* req_agent, 
 /* The same launch sized before the host knows the number of requests: n_max is an upper bound, *n_live (memory the
  * device can read, written by the kernel that counted the requests - flm_rollout_alt_finish's counts[2] - earlier on
  * the same stream) their number; requests from *n_live on are skipped.  out holds n_max rows.  A caller uses it to
- * enqueue the observations first and wait for the count afterwards, instead of leaving the device idle meanwhile. */
+ * enqueue the observations first and wait for the count afterwards, instead of leaving the device idle meanwhile.
+ * plane_limit (0 = plane_stride; a multiple of 16): only the first plane_limit bytes of every plane are written.  With
+ * observations padded to max_rails the rails beyond the environments' own are zero: a caller whose buffer holds zeros
+ * there (and who raises the limit, or clears the buffer, when the rail count changes) saves writing them every step. */
 int flm_observations_req_columns_counted(const int16_t* cols, const int32_t* req_agent, const int16_t* own_cols,
-                                         const int32_t* own_row, int n_max, const int32_t* n_live, int E, int A, int Rp,
-                                         int T1, int plane_stride, uint8_t* out, void* stream);
+                                         const int32_t* own_row, int n_max, const int32_t* n_live, int plane_limit, int E,
+                                         int A, int Rp, int T1, int plane_stride, uint8_t* out, void* stream);
 
 /* flm_observations_req_columns of the agents' own planes, written to chosen rows: request g goes to row
  * out_row[g] of out [.,3,plane_stride] (a negative out_row[g] skips the request).  The training loop's

@@ -171,7 +171,17 @@ def test_counted_launches_match_the_sized_ones():
     got_o = torch.full((m + 5, 3, b.plane_stride), 9, dtype=torch.uint8, device=dev)
     live_o = torch.tensor([m], **i32)
     agents_pad = torch.cat([agents, torch.full((5,), 10 ** 6, **i32)])
-    call("flm_observations_req_columns_counted", ptr(ro.cols), ptr(agents_pad), None, None, m + 5, ptr(live_o), ro.E, ro.A,
+    call("flm_observations_req_columns_counted", ptr(ro.cols), ptr(agents_pad), None, None, m + 5, ptr(live_o), 0, ro.E, ro.A,
          b.Rp, b.T1, b.plane_stride, ptr(got_o), ro.stream)
     torch.cuda.synchronize()
     assert torch.equal(got_o[:m], want_o) and bool((got_o[m:] == 9).all()) and int(want_o.max()) > 0
+    # ... and with only the rails the environments have written: the same bytes there, the rest left alone
+    limit = ro.plane_bytes_used()
+    assert 0 < limit < b.plane_stride and limit % 16 == 0 and limit >= ro.rails_used() * b.T1
+    assert not bool(want_o[:, :, limit:].any())                   # what lies behind is zero in the full observation
+    got_l = torch.full((m + 5, 3, b.plane_stride), 9, dtype=torch.uint8, device=dev)
+    call("flm_observations_req_columns_counted", ptr(ro.cols), ptr(agents_pad), None, None, m + 5, ptr(live_o), limit, ro.E,
+         ro.A, b.Rp, b.T1, b.plane_stride, ptr(got_l), ro.stream)
+    torch.cuda.synchronize()
+    assert torch.equal(got_l[:m, :, :limit], want_o[:, :, :limit]) and bool((got_l[:m, :, limit:] == 9).all())
+    assert bool((got_l[m:] == 9).all())
