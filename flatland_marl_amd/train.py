@@ -104,6 +104,7 @@ class DQNPolicy:
         if self._flat is None:
             self.prepare(ro)
         flat, self._flat = self._flat, None
+        q_done = False
         if alt is not None:
             # departing agents + all alternatives: at most n1 + n2 * cap_alt rows.  The observations are enqueued for that
             # many (the kernel skips the rows beyond the number its predecessor counted), then the host waits for the number
@@ -118,7 +119,18 @@ class DQNPolicy:
                     obs_pool.zero_()
                 self._pool_limit = limit
                 ro.consult_observations_counted(pool["row_req"], pool["cols"], pool["row_own"], obs_pool, rows_max, limit)
+                # what the forward pass needs apart from the number of rows is put together before the wait, so that
+                # the launch follows it at once (the same call as Dueling_DQN.forward_obs makes)
+                net_l, b = self.agent.qnetwork_local, ro.b
+                fast = rows_max <= max(1, self.chunk_bytes // (64 * 3 * b.Rp * 4))
+                if fast:
+                    head = (ptr(flat), ptr(obs_pool))
+                    tail = (b.Rp, net_l.width, b.plane_stride, net_l.action_space, ro.rails_used(),
+                            ptr(net_l._workspace(rows_max)), ptr(q_pool), ro.stream)
                 rows = ro.wait_counts()[2]
+                if fast and rows:
+                    call("flm_dqn_forward_u8_rails", *head, rows, *tail)
+                    q_done = True
                 obs = obs_pool[:rows]
             else:
                 rows = ro.read_counts()[2]
@@ -134,7 +146,7 @@ class DQNPolicy:
             self._pool_limit = ro.b.plane_stride            # (whole planes written)
         if rows == 0:                                       # agents before a switch, none with an alternative
             return net, best
-        q = self.q_values(ro, obs, out=q_pool, flat=flat)
+        q = q_pool[:rows] if q_done else self.q_values(ro, obs, out=q_pool, flat=flat)
         sel_row, sel_act = self._sel[0][:n1 + n2], self._sel[1][:n1 + n2]
         call("flm_policy_select", ptr(q), ptr(req1) if n1 else None, n1, ptr(req2) if n2 else None, n2,
              ptr(alt["row_offset"]) if alt is not None else None, ptr(alt["count"]) if alt is not None else None,
