@@ -332,8 +332,8 @@ class RolloutBatch:
             pool = self._alt_pool_for(launched, 0)
             p_count, p_len, p_cell, p_meta, p_err = pool["base"]
             call("flm_altpaths_counted", *tables[0], ptr(self.switch_list), launched, self.req_counts.data_ptr() + 4, 0,
-                 pool["agent_rep"].data_ptr(), *tables[1], self.E, self.A, b.H, b.W, b.cap_cells, self.max_alt_depth, self.cap_alt, self.Lp, p_count, p_len,
-                 p_cell, p_meta, p_err, self.stream)
+                 pool["agent_rep"].data_ptr(), *tables[1], self.E, self.A, b.H, b.W, b.cap_cells, self.max_alt_depth,
+                 self.cap_alt, self.Lp, p_count, p_len, p_cell, p_meta, p_err, self.stream)
         n_ready, n_switch = self.wait_counts()[:2]             # the host waits for the step's sizes
         self._alt_guess = n_switch + n_switch // 4 + 32 if n_switch else 0
         req_ready, req_switch = self.ready_list[:n_ready], self.switch_list[:n_switch]
