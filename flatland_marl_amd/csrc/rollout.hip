@@ -54,55 +54,65 @@ __global__ __launch_bounds__(64) void altpaths_kernel(
   const uint16_t* succ = succ_all ? succ_all + (size_t)e * capCells * 4 : nullptr;
   const uint16_t* choice = succ_all && choice_all ? choice_all + (size_t)e * capCells * 16 : nullptr;
   // STAGE: [capCells * 4] next move, [capCells * 4] the move after it (32 bits each), [capCells] grid cell of every rail
-  // cell, then the descents' records [cap_alt][Lcap]; before the descents that last region holds copies of the
-  // environment's choice table (8 bytes per state), successor table and the target's distance row (2 bytes per state
-  // each), from which the move tables are worked out (capCells is even: every table is whole 16-byte pieces)
+  // cell, then the descents' records [cap_alt][Lcap]; before the descents that last region holds a copy of the target's
+  // distance row (2 bytes per state), from which - with the environment's successor and choice tables, read from
+  // memory - the move tables are worked out (capCells is even: every table is whole 16-byte pieces)
   uint32_t* next_lds = reinterpret_cast<uint32_t*>(alt_frames + FLM_ALT_FRAME_INTS);
   uint32_t* next2_lds = next_lds + (size_t)capCells * 4;
   int32_t* icell_lds = reinterpret_cast<int32_t*>(next2_lds + (size_t)capCells * 4);
   uint32_t* rec_lds = reinterpret_cast<uint32_t*>(icell_lds + ((capCells + 3) & ~3));   // (on a 16-byte boundary)
-  uint16_t* choice_lds = reinterpret_cast<uint16_t*>(rec_lds);
-  uint16_t* succ_lds = choice_lds + (size_t)capCells * 16;
-  uint16_t* dist_lds = succ_lds + (size_t)capCells * 4;
+  uint16_t* dist_lds = reinterpret_cast<uint16_t*>(rec_lds);
   constexpr uint32_t NO_MOVE = 0xFFFFFFFFu;
   const int tcell_s = target_cell[ga];
   const int tci_s = (STAGE && tcell_s >= 0 && tcell_s < HW) ? cell_idx[tcell_s] : -1;
   if (STAGE) {
     // (G = 64: the whole wave serves one request, e and the target are the same for every lane)
-    const uint4* src_c = reinterpret_cast<const uint4*>(choice);
-    const uint4* src_s = reinterpret_cast<const uint4*>(succ);
+    // Only the target's distance row is looked up at random (by successor state): it is staged.  The successor table
+    // is read once, front to back, and the choice table once per state that has a choice: both come straight from
+    // memory, eight states per lane and pass, which keeps the request's LDS at 44 bytes per cell - five requests
+    // per CU instead of two.
     const uint4* src_d = reinterpret_cast<const uint4*>(dist);
     const int32_t* src_i = idx_cell_all + (size_t)e * capCells;
-    uint4* dst_c = reinterpret_cast<uint4*>(choice_lds);
-    uint4* dst_s = reinterpret_cast<uint4*>(succ_lds);
     uint4* dst_d = reinterpret_cast<uint4*>(dist_lds);
-    for (int i = lane; i < capCells * 2; i += 64) dst_c[i] = src_c[i];   // capCells * 32 bytes, 16 per copy
-    for (int i = lane; i < capCells / 2; i += 64) {                      // capCells * 8 bytes each
-      dst_s[i] = src_s[i];
-      dst_d[i] = src_d[i];
-    }
+    for (int i = lane; i < capCells / 2; i += 64) dst_d[i] = src_d[i];   // capCells * 8 bytes, 16 per copy
     for (int i = lane; i < capCells; i += 64) icell_lds[i] = src_i[i];
     __syncthreads();
-    const int capS = capCells * 4;
-    for (int st = lane; st < capS; st += 64) {
-      const unsigned nx = succ_lds[st];
-      uint32_t w = NO_MOVE;
-      if (nx != 0xFFFFu) {
-        w = nx | (2u << 16);                                   // forced: recorded as "forward"
-      } else {
-        const uint2 raw = *reinterpret_cast<const uint2*>(choice_lds + (size_t)st * 4);
-        const unsigned ns[3] = {raw.x & 0xFFFFu, raw.x >> 16, raw.y & 0xFFFFu};
-        unsigned best_d = 0xFFFFFFFFu;
+    const int capS = capCells * 4;                             // (a multiple of 8: capCells is even)
+    for (int s8 = lane * 8; s8 < capS; s8 += 64 * 8) {
+      const uint4 sv = *reinterpret_cast<const uint4*>(succ + s8);
+      const unsigned sw[4] = {sv.x, sv.y, sv.z, sv.w};
+      unsigned nx[8];
+      uint2 raw[8];
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-          const unsigned dd = ns[i] != 0xFFFFu ? (unsigned)dist_lds[ns[i]] : (unsigned)FLM_DIST_INF;
-          if (dd != FLM_DIST_INF && dd < best_d) {
-            best_d = dd;
-            w = ns[i] | (((raw.y >> 16) & 1u ? 2u : (unsigned)(1 + i)) << 16);
+      for (int k = 0; k < 8; k++) {
+        nx[k] = (sw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+        raw[k] = make_uint2(0u, 0u);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (nx[k] == 0xFFFFu) raw[k] = *reinterpret_cast<const uint2*>(choice + (size_t)(s8 + k) * 4);
+      uint32_t wv[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        uint32_t w = NO_MOVE;
+        if (nx[k] != 0xFFFFu) {
+          w = nx[k] | (2u << 16);                              // forced: recorded as "forward"
+        } else {
+          const unsigned ns[3] = {raw[k].x & 0xFFFFu, raw[k].x >> 16, raw[k].y & 0xFFFFu};
+          unsigned best_d = 0xFFFFFFFFu;
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            const unsigned dd = ns[i] != 0xFFFFu ? (unsigned)dist_lds[ns[i]] : (unsigned)FLM_DIST_INF;
+            if (dd != FLM_DIST_INF && dd < best_d) {
+              best_d = dd;
+              w = ns[i] | (((raw[k].y >> 16) & 1u ? 2u : (unsigned)(1 + i)) << 16);
+            }
           }
         }
+        wv[k] = w;
       }
-      next_lds[st] = w;
+      *reinterpret_cast<uint4*>(next_lds + s8) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+      *reinterpret_cast<uint4*>(next_lds + s8 + 4) = make_uint4(wv[4], wv[5], wv[6], wv[7]);
     }
     __syncthreads();
     // the move after the next one; none where the next state is on the target cell (a walk ends there)
@@ -503,7 +513,7 @@ static int altpaths_impl(const uint16_t* grid, const int32_t* cell_idx, const ui
   // one request per wave with its move tables, the cell table and the descents' records in LDS when the successor and
   // choice tables exist, are 8-byte aligned per environment (an even capCells) and everything fits beside the frames
   const size_t staged_lds = (size_t)FLM_ALT_FRAME_INTS * sizeof(int) + (size_t)capCells * 32 + (size_t)((capCells + 3) & ~3) * 4 +
-                            std::max((size_t)capCells * 48, (size_t)cap_alt * Lcap * 4) + 16;
+                            std::max((size_t)capCells * 8, (size_t)cap_alt * Lcap * 4) + 16;
   const bool stage = succ && choice && idx_cell && (capCells & 1) == 0 && capCells * 4 <= 65535 &&
                      (((uintptr_t)succ | (uintptr_t)choice | (uintptr_t)dist) & 15) == 0 && staged_lds <= 64 * 1024;
   if (stage) {
